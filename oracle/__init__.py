@@ -1,0 +1,29 @@
+"""CPU restatement of the kooBH/UNet hot path -- TEST INFRASTRUCTURE ONLY.
+
+This package is the parity checker for the HIP path in ``unet_amd``: plain
+``torch.nn`` CPU modules that restate, layer for layer, what the reference's
+``UNet`` / ``cRFUNet.UNet20`` / ``ResUNet`` / ``DSUNet`` compute.  It is imported
+only by ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py``.  Nothing under ``unet_amd/`` imports it and the product never
+routes a forward through it.
+
+Pinning: ``oracle/check_against_reference.py`` (run in the build container,
+where the reference checkout is importable) loads identical seeded
+state_dicts into the reference modules and into these, and requires
+``torch.equal`` outputs in eval mode, in train mode and for gradients.  The
+same script writes the golden vectors under ``tests/golden/`` that pin the
+oracle where the reference checkout is absent (the GPU box).
+"""
+
+from .blocks import (Encoder, Decoder, ResBlock, DSEncoder, DSDecoder, Attractor,
+                     AttractEncoder, CRM)
+from .nets import UNet, UNet20, ResUNet, DSUNet
+from .tables import unet20_layers, default_unet, dsunet_architecture
+from .masking import crf_apply, resunet_mask_apply, crm_apply
+
+__all__ = [
+    "Encoder", "Decoder", "ResBlock", "DSEncoder", "DSDecoder", "Attractor",
+    "AttractEncoder", "CRM", "UNet", "UNet20", "ResUNet", "DSUNet",
+    "unet20_layers", "default_unet", "dsunet_architecture",
+    "crf_apply", "resunet_mask_apply", "crm_apply",
+]

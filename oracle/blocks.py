@@ -1,0 +1,215 @@
+"""Building blocks of the oracle (CPU, stock torch ops).  Test infrastructure.
+
+Every class states which reference block it restates.  Submodule names are
+the reference's, so a reference ``state_dict`` loads unchanged.
+"""
+
+import torch
+import torch.nn as nn
+
+
+def _make_activation(name, where):
+    """Activation by the reference's string switch (UNet_m.py:324-337)."""
+    if name == "LeakyReLU":
+        return nn.LeakyReLU(inplace=True)
+    if name == "SiLU":
+        return nn.SiLU(inplace=True)
+    if name == "Softplus":
+        return nn.Softplus()
+    if name == "PReLU":
+        return nn.PReLU()
+    if name == "ReLU":
+        return nn.ReLU()
+    if name == "GELU":
+        return nn.GELU()
+    raise Exception("ERROR::{}:Unknown activation type {}".format(where, name))
+
+
+def _norm_class(name):
+    """Normalisation by the reference's string switch (UNet_m.py:312-319)."""
+    table = {"BatchNorm2d": nn.BatchNorm2d, "InstanceNorm2d": nn.InstanceNorm2d,
+             "LayerNorm": nn.LayerNorm}
+    if name not in table:
+        raise Exception("ERROR::Encoder: unknown normalization - {}".format(name))
+    return table[name]
+
+
+class Encoder(nn.Module):
+    """Conv2d -> Dropout -> norm -> activation.  Restates UNet_m.py:304-345."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding=None,
+                 dilation=1, norm="BatchNorm2d", padding_mode="zeros", dropout=0.0,
+                 activation="LeakyReLU"):
+        super().__init__()
+        if padding is None:  # 'same' padding for odd kernels, UNet_m.py:307-308
+            padding = [(k - 1) // 2 for k in kernel_size]
+        norm_cls = _norm_class(norm)
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size,
+                              stride=stride, padding=padding, dilation=dilation,
+                              padding_mode=padding_mode)
+        self.bn = norm_cls(out_channels)
+        self.acti = _make_activation(activation, "Encoder")
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        return self.acti(self.bn(self.dropout(self.conv(x))))
+
+
+class Decoder(nn.Module):
+    """ConvTranspose2d -> norm -> activation.  Restates UNet_m.py:347-383."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding=(0, 0),
+                 dilation=1, output_padding=(0, 0), activation="LeakyReLU",
+                 norm="BatchNorm2d"):
+        super().__init__()
+        norm_cls = _norm_class(norm)
+        self.transconv = nn.ConvTranspose2d(in_channels, out_channels,
+                                            kernel_size=kernel_size, stride=stride,
+                                            dilation=dilation,
+                                            output_padding=output_padding,
+                                            padding=padding)
+        self.bn = norm_cls(out_channels)
+        self.acti = _make_activation(activation, "Encoder")
+
+    def forward(self, x):
+        return self.acti(self.bn(self.transconv(x)))
+
+
+class ResBlock(nn.Module):
+    """Five [depthwise 3x3 dilated along time -> pointwise 1x1 -> PReLU -> BN]
+    layers; the first replaces x, the others add to the running value.
+    Restates UNet_m.py:518-563.  ONE PReLU instance is shared by the five layers
+    (UNet_m.py:528-529,551), so ``res_{0..4}.2.weight`` alias one tensor.
+    """
+
+    TIME_DILATIONS = (1, 2, 4, 8, 16)
+
+    def __init__(self, n_channel, norm="BatchNorm2d", dropout=0.0, activation="PReLU"):
+        super().__init__()
+        if norm != "BatchNorm2d":
+            raise Exception("ERROR::ResBlock: unknown nromalization - {}".format(norm))
+        if activation != "PReLU":
+            # the reference's GELU branch leaves its local unset and fails at use
+            # (UNet_m.py:530-531,551); anything else raises at :533
+            raise Exception("ERROR::ResBlock:Unknown activation type " + str(activation))
+        shared_act = nn.PReLU()
+        self.layers = []
+        for i, d in enumerate(self.TIME_DILATIONS):
+            layer = nn.Sequential(
+                nn.Conv2d(n_channel, n_channel, (3, 3), (1, 1), padding=(1, d),
+                          dilation=(1, d), groups=n_channel),
+                nn.Conv2d(n_channel, n_channel, (1, 1)),
+                shared_act,
+                nn.BatchNorm2d(n_channel),
+            )
+            self.add_module("res_{}".format(i), layer)
+            self.layers.append(layer)
+
+    def forward(self, x):
+        r = self.layers[0](x)
+        for layer in self.layers[1:]:
+            r = torch.add(r, layer(r))
+        return r
+
+
+# ----------------------------------------------------------------------------
+# DSUNet's own block copies (different ctor signature from UNet_m's)
+# ----------------------------------------------------------------------------
+
+def _ds_activation(name):
+    """DSUNet.py:79-86 / :187-194 -- no error branch: unknown names leave the
+    attribute unset in the reference; here they raise KeyError at construction."""
+    return {"LeakyReLU": lambda: nn.LeakyReLU(inplace=True), "PReLU": nn.PReLU,
+            "SiLU": nn.SiLU, "Softplus": nn.Softplus}[name]()
+
+
+def _ds_norm(type_norm):
+    return {"BatchNorm2d": nn.BatchNorm2d, "InstanceNorm2d": nn.InstanceNorm2d}[type_norm]
+
+
+class DSEncoder(nn.Module):
+    """DSUNet's Encoder: conv -> dropout -> norm -> act.  Restates DSUNet.py:62-93."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding=None,
+                 padding_mode="zeros", activation="LeakyReLU", dropout=0.0,
+                 type_norm="BatchNorm2d"):
+        super().__init__()
+        if padding is None:
+            padding = [(k - 1) // 2 for k in kernel_size]
+        self.dr = nn.Dropout(dropout)
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size,
+                              stride=stride, padding=padding, padding_mode=padding_mode)
+        self.bn = _ds_norm(type_norm)(out_channels)
+        self.relu = _ds_activation(activation)
+
+    def forward(self, x):
+        return self.relu(self.bn(self.dr(self.conv(x))))
+
+
+class DSDecoder(nn.Module):
+    """DSUNet's Decoder: tconv -> norm -> act; ``output_padding`` is positional
+    BEFORE ``padding``.  Restates DSUNet.py:174-200."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, output_padding,
+                 padding=(0, 0), activation="LeakyReLU", type_norm="BatchNorm2d"):
+        super().__init__()
+        self.transconv = nn.ConvTranspose2d(in_channels, out_channels,
+                                            kernel_size=kernel_size, stride=stride,
+                                            output_padding=output_padding,
+                                            padding=padding)
+        self.bn = _ds_norm(type_norm)(out_channels)
+        self.relu = _ds_activation(activation)
+
+    def forward(self, x):
+        return self.relu(self.bn(self.transconv(x)))
+
+
+class Attractor(nn.Module):
+    """MLP from steering vector + angle to a 256-dim code.  Restates DSUNet.py:11-43."""
+
+    def __init__(self, n_ch=4, n_fft=512):
+        super().__init__()
+        n_bins = n_fft // 2 + 1
+        self.enc_SV = nn.Linear(n_ch * (n_fft + 2), n_bins)
+        self.act_SV = nn.PReLU()
+        self.enc_theta = nn.Linear(2, n_bins)
+        self.act_theta = nn.Sigmoid()
+        self.bn = nn.BatchNorm1d(n_bins)
+        self.enc_2 = nn.Linear(n_bins, n_fft + 2)
+        self.act_2 = nn.PReLU()
+        self.enc_3 = nn.Linear(n_fft + 2, n_fft // 2)
+        self.act_3 = nn.Sigmoid()
+
+    def forward(self, SV, theta):
+        sv = self.act_SV(self.enc_SV(SV.reshape(SV.shape[0], -1)))
+        th = self.act_theta(self.enc_theta(theta))
+        h = self.bn(sv + th)
+        h = self.act_2(self.enc_2(h))
+        return self.act_3(self.enc_3(h))
+
+
+class AttractEncoder(nn.Module):
+    """Per-layer channel gate max(sigmoid(Linear(code)), 1/C).  Restates
+    DSUNet.py:45-60 (the Conv1d member is constructed but never used)."""
+
+    def __init__(self, n_ch, n_fft=512):
+        super().__init__()
+        self.n_ch = n_ch
+        self.enc = nn.Linear(n_fft // 2, n_ch)
+        self.conv = nn.Conv1d(1, n_ch, kernel_size=1)
+        self.act = nn.Sigmoid()
+
+    def forward(self, attract):
+        return torch.clamp(self.act(self.enc(attract)), min=1 / self.n_ch)
+
+
+class CRM(nn.Module):
+    """Complex ratio mask head: tanh, channels (0,1) -> complex.  Restates
+    DSUNet.py:351-362."""
+
+    def forward(self, x):
+        m = torch.tanh(x)
+        return m[:, 0, ...] + 1j * m[:, 1, ...]
+
+    def output(self, X, M):
+        return X * M

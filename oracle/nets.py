@@ -1,0 +1,264 @@
+"""Network assemblies of the oracle (CPU, stock torch ops).  Test infrastructure.
+
+Restates the four ``forward`` bodies on the hot path.  Registered submodule
+names equal the reference's so its ``state_dict`` loads unchanged.
+"""
+
+import torch
+import torch.nn as nn
+
+from .blocks import (Encoder, Decoder, ResBlock, DSEncoder, DSDecoder, Attractor,
+                     AttractEncoder, CRM)
+from .tables import unet20_layers
+
+
+def _register_concat_shell(net, encoders, decoders, bottlenecks, res_paths):
+    """Module registration shared by UNet and UNet20 (UNet.py:26-66,
+    cRFUNet.py:227-267): ``encoder_i``/``decoder_i``, identity ``res_path{i}``
+    (L entries: L-1 real + one dummy) and identity ``bottleneck0`` by default."""
+    n = len(encoders)
+    net.len_model = n
+    net.encoders, net.decoders = encoders, decoders
+    for i, m in enumerate(encoders):
+        net.add_module("encoder_{}".format(i), m)
+    for i, m in enumerate(decoders):
+        net.add_module("decoder_{}".format(i), m)
+    net.res_paths = []
+    if res_paths is not None:
+        if len(res_paths) != n - 1:
+            raise Exception("ERROR::unmatched res_path : {} != {}".format(len(res_paths), n - 1))
+        paths = list(res_paths)
+    else:
+        paths = [nn.Identity() for _ in range(n - 1)]
+    paths.append(nn.Identity())  # slot for the last encoder's input; value never used
+    for i, m in enumerate(paths):
+        net.add_module("res_path{}".format(i), m)
+        net.res_paths.append(m)
+    net.bottlenecks = list(bottlenecks) if bottlenecks is not None else [nn.Identity()]
+    for i, m in enumerate(net.bottlenecks):
+        net.add_module("bottleneck{}".format(i), m)
+
+
+def _concat_shell_forward(net, x):
+    """Encoder loop, bottleneck, decoder loop with [decoder, skip] concat
+    (UNet.py:85-106 == cRFUNet.py:290-311)."""
+    skips = []
+    for i, enc in enumerate(net.encoders):
+        skips.append(net.res_paths[i](x))
+        x = enc(x)
+    p = x
+    for b in net.bottlenecks:
+        p = b(p)
+    last = net.len_model - 1
+    for i, dec in enumerate(net.decoders):
+        p = dec(p)
+        if i == last:
+            break
+        p = torch.cat([p, skips[last - i]], dim=1)
+    return p
+
+
+class UNet(nn.Module):
+    """Generic concat-skip U-Net around caller-built block lists; 1x1 conv(1->1)
+    + Sigmoid mask head.  Restates UNet.py:6-113.
+
+    The reference constructor reads an undefined global ``print_shape``
+    (UNet.py:24) and only works after that name is injected into its module;
+    here it is a keyword that defaults to False.
+    """
+
+    def __init__(self, encoders, decoders, bottlenecks=None, res_paths=None,
+                 device="cuda:0", print_shape=False):
+        super().__init__()
+        self.device = device
+        if len(encoders) != len(decoders):
+            raise Exception("ERROR::unmatched legnth : enc {} != dec {}".format(
+                len(encoders), len(decoders)))
+        self.print_shape = print_shape
+        _register_concat_shell(self, encoders, decoders, bottlenecks, res_paths)
+        self.add_module("linear", nn.Conv2d(1, 1, 1))
+        self.activation_mask = nn.Sigmoid()
+
+    def forward(self, x):
+        p = _concat_shell_forward(self, x)
+        return self.activation_mask(self.linear(p))
+
+
+class UNet20(nn.Module):
+    """cRFUNet's 10+10-layer net: fixed table, 1x1 head to 2*c_out*N channels,
+    Softplus (or Sigmoid), then a RAW reshape of the NCHW buffer to
+    [B,N,c_out,2L_f+1,2L_t+1,F,T,2] viewed as complex (adjacent TIME frames pair
+    up as re/im).  Restates cRFUNet.py:162-324."""
+
+    def __init__(self, c_in=4 + 6 + 4, c_out=4, L_t=0, L_f=0, n_target=4, n_feature=12,
+                 n_fft=512, device="cuda:0", print_shape=False, mask="Softplus"):
+        super().__init__()
+        self.print_shape = print_shape
+        self.N, self.C, self.c_out = n_target, c_in, c_out
+        self.L_t, self.L_f = L_t, L_f
+        self.F = int(n_fft / 2 + 1)
+        self.T = 125  # hard-coded in the reference (cRFUNet.py:187); callers overwrite it
+        f_dim = 32
+        enc_rows, dec_rows = unet20_layers(c_in=c_in, c_last=2 * f_dim, f_dim=f_dim)
+        encoders = [Encoder(*r["args"], **r["kw"]) for r in enc_rows]
+        decoders = [Decoder(*r["args"], **r["kw"]) for r in dec_rows]
+        self.linear = nn.Conv2d(2 * f_dim, 2 * c_out * n_target, 1)
+        _register_concat_shell(self, encoders, decoders, None, None)
+        self.activation_mask = nn.Sigmoid() if mask == "Sigmoid" else nn.Softplus()
+
+    def forward(self, x):
+        p = _concat_shell_forward(self, x)
+        f = self.activation_mask(self.linear(p))
+        f = torch.reshape(f, (f.shape[0], self.N, self.c_out, 2 * self.L_f + 1,
+                              2 * self.L_t + 1, self.F, self.T, 2))
+        return torch.view_as_complex(f)
+
+
+class ResUNet(nn.Module):
+    """Frequency-strided residual U-Net with additive skips through 1x1
+    res-paths and a projected-LSTM bottleneck; output = (tanh(y)+1e-13) * input[:, :2].
+    Restates ResUNet.py:22-220."""
+
+    def __init__(self, c_in=4, c_out=1, n_fft=512, device="cuda:0", output="mapping",
+                 print_shape=False, T=125):
+        super().__init__()
+        n_hfft = int(n_fft / 2 + 1)
+        self.print_shape = print_shape
+        self.F, self.T = n_hfft, T
+        C = 64
+        prelu = dict(activation="PReLU")
+
+        # input layers act on [B,C,T,F]: conv along F, LayerNorm over F (ResUNet.py:47-54)
+        self.layer_data = nn.Sequential(Encoder(c_in - 2, 20, (1, 3), 1, (0, 1), 1),
+                                        nn.LayerNorm(n_hfft))
+        self.layer_AF = nn.Sequential(Encoder(2, C - 20, (1, 3), 1, (0, 1), 1),
+                                      nn.LayerNorm(n_hfft))
+
+        def down():  # ResUNet.py:59-78
+            return nn.Sequential(Encoder(C, C, (3, 3), (2, 1), (0, 1), **prelu), ResBlock(C))
+
+        def up(pad, opad):  # ResUNet.py:94-113
+            return nn.Sequential(ResBlock(C), Decoder(C, C, (4, 1), (2, 1), pad,
+                                                      output_padding=opad, **prelu))
+
+        self.encoders = [ResBlock(C)] + [down() for _ in range(5)] + [
+            Encoder(C, 2 * C, (3, 1), (2, 1), (0, 0), **prelu),
+            Encoder(2 * C, 6 * C, (3, 1), (1, 1), (0, 0), **prelu)]
+        for i, m in enumerate(self.encoders):
+            self.add_module("enc_{}".format(i), m)
+
+        self.decoders = [
+            Decoder(6 * C, 2 * C, (3, 1), (1, 1), (0, 0), **prelu),
+            Decoder(2 * C, C, (4, 1), (2, 1), (1, 0), output_padding=(1, 0), **prelu),
+            up((1, 0), (1, 0)), up((1, 0), (1, 0)), up((1, 0), (1, 0)),
+            up((0, 0), (0, 0)), up((1, 0), (1, 0)),
+            ResBlock(C)]
+        for i, m in enumerate(self.decoders):
+            self.add_module("dec_{}".format(i), m)
+        self.len_model = len(self.encoders)
+
+        widths = [C] * 6 + [2 * C, 6 * C]  # ResUNet.py:125-132
+        self.res_paths = [Encoder(w, w, 1, 1, 0, 1, **prelu) for w in widths]
+        for i, m in enumerate(self.res_paths):
+            self.add_module("res_path_{}".format(i), m)
+
+        self.bottleneck = nn.LSTM(6 * C, 10 * C, 3, batch_first=True, proj_size=6 * C)
+        self.out_layer = nn.ConvTranspose2d(C, 2, (3, 1), stride=1, padding=(1, 0),
+                                            dilation=1, output_padding=(0, 0))
+        self.last_activation = nn.Tanh()
+
+    def forward(self, input):
+        feat = torch.permute(input[:, :-2, :, :], (0, 1, 3, 2))
+        af = torch.permute(input[:, -2:, :, :], (0, 1, 3, 2))
+        feat = torch.permute(self.layer_data(feat), (0, 1, 3, 2))
+        af = torch.permute(self.layer_AF(af), (0, 1, 3, 2))
+        x = torch.cat((feat, af), dim=1)
+
+        res = []
+        for enc in self.encoders:
+            x = enc(x)
+            res.append(x)
+
+        # [B,C,1,T] -> [B,T,C] -> LSTM -> back (ResUNet.py:186-197)
+        x = torch.reshape(x, (x.shape[0], x.shape[1], x.shape[3]))
+        x = self.bottleneck(torch.permute(x, (0, 2, 1)))[0]
+        x = torch.permute(x, (0, 2, 1))
+        x = torch.reshape(x, (x.shape[0], x.shape[1], 1, x.shape[2]))
+
+        for i, rp in enumerate(self.res_paths):
+            res[i] = rp(res[i])
+
+        y = x
+        for i, dec in enumerate(self.decoders):
+            y = dec(torch.add(y, res[-1 - i]))
+
+        mask = self.last_activation(self.out_layer(y)) + 1e-13
+        return torch.mul(mask, input[:, :2, :, :])
+
+
+class DSUNet(nn.Module):
+    """Directional-separating U-Net built from an external architecture dict
+    (keys ``encoder.enc{1..L}`` / ``decoder.dec{L..1}``); each encoder output is
+    gated per (batch, channel) by a code of steering vector + angle; CRM head.
+    Restates DSUNet.py:467-631 for type_encoder="Encoder", bottleneck="None",
+    type_residual="None", type_masking="CRM" (the defaults)."""
+
+    def __init__(self, architecture, input_channels=8, n_fft=512, model_complexity=45,
+                 bottleneck="None", padding_mode="zeros", type_masking="CRM",
+                 activation="LeakyReLU", dropout=0.0, type_norm="BatcNorm2d",
+                 type_encoder="Encoder", type_residual="None"):
+        super().__init__()
+        if type_encoder != "Encoder" or type_masking != "CRM" or bottleneck != "None" \
+                or type_residual != "None":
+            raise Exception("Not Implemented")
+        self.bottleneck = bottleneck
+        self.n_channel = input_channels
+        self.dropout = dropout
+        L = self.n_layer = len(architecture["encoder"])
+        enc_kw = [architecture["encoder"]["enc{}".format(i + 1)] for i in range(L)]
+        dec_kw = [architecture["decoder"]["dec{}".format(L - i)] for i in range(L)]
+
+        encs = [DSEncoder(**kw) for kw in enc_kw]
+        for i, m in enumerate(encs):
+            self.add_module("encoder{}".format(i), m)
+        decs = [DSDecoder(**kw) for kw in dec_kw]
+        for i, m in enumerate(decs):
+            self.add_module("decoder{}".format(i), m)
+        self.BTN = nn.Identity()
+        res = [nn.Identity() for _ in range(L - 1)]
+        for i, m in enumerate(res):
+            self.add_module("res{}".format(i), m)
+        self.Attractor = Attractor(n_ch=4, n_fft=n_fft)
+        self.attractEncoders = [AttractEncoder(n_ch=kw["out_channels"]) for kw in enc_kw]
+        for i, m in enumerate(self.attractEncoders):
+            self.add_module("attractEncoder_{}".format(i), m)
+        self.add_module("linear", nn.Conv2d(architecture["decoder"]["dec1"]["out_channels"], 2, 1))
+        self.padding_mode = padding_mode
+        self.mask = CRM()
+        self.dr = nn.Dropout(self.dropout)
+        # the reference re-registers the same modules in ModuleLists
+        # (DSUNet.py:577-580), which doubles their state_dict keys
+        self.decoders = nn.ModuleList(decs)
+        self.encoders = nn.ModuleList(encs)
+        self.attractors = nn.ModuleList(self.attractEncoders)
+        self.res = nn.ModuleList(res)
+
+    def forward(self, sf, SV, theta):
+        attract = self.Attractor(SV, theta)
+        L = self.n_layer
+        skips = []
+        for i, enc in enumerate(self.encoders):
+            skips.append(self.res[i](sf) if i != L - 1 else sf)
+            sf = self.dr(enc(sf))
+            gate = self.attractEncoders[i](attract)
+            sf = torch.reshape(gate, (*gate.shape, 1, 1)) * sf
+        p = self.BTN(sf)
+        for i, dec in enumerate(self.decoders):
+            p = dec(p)
+            if i == L - 1:
+                break
+            p = torch.cat([p, skips[L - 1 - i]], dim=1)
+        return self.mask(self.linear(p))
+
+    def masking(self, X, M):
+        return self.mask.output(X, M)

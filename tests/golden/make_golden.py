@@ -1,0 +1,256 @@
+"""Pin the oracle against the reference and write the golden vectors.
+
+Run ONLY in the build container, where the reference checkout is importable:
+
+    python tests/golden/make_golden.py [--reference /root/reference] [--check-only]
+
+For every model on the hot path it (1) builds the reference module and the
+oracle module, fills the reference with ``unet_amd.seeding.seeded_fill_`` and
+copies its ``state_dict`` into the oracle with ``strict=True`` (which also pins
+key compatibility), (2) requires ``torch.equal`` outputs in eval mode and, for
+the training-step model, equal loss / gradients / post-Adam parameters, and
+(3) writes small fixtures -- inputs are regenerated from a seed, so a fixture
+holds only expected outputs (full tensor when small, else fixed samples plus
+float64 checksums) -- to ``tests/golden/*.npz``.
+
+The reference's files are only imported here; nothing of them is stored.
+``UNet.py`` reads an undefined module global ``print_shape`` in its
+constructor (UNet.py:24), so that name is injected into the imported module;
+no reference file is edited.
+"""
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+from oracle.tables import unet20_layers, dsunet_architecture  # noqa: E402
+from unet_amd.seeding import seeded_fill_, normal, uniform  # noqa: E402
+
+N_SAMPLES = 2048
+
+
+def sample_index(numel, n=N_SAMPLES):
+    """Fixed pseudo-random flat indices (a pure function of numel)."""
+    if numel <= n:
+        return np.arange(numel, dtype=np.int64)
+    step = numel / n
+    return (np.arange(n) * step + (np.arange(n) * 7919) % max(int(step), 1)).astype(np.int64) % numel
+
+
+def summarise(t):
+    """dict(sum, sumsq, samples) of a real or complex tensor, float64 sums."""
+    if t.is_complex():
+        t = torch.view_as_real(t)
+    flat = t.detach().reshape(-1).double().numpy()
+    idx = sample_index(flat.size)
+    return dict(sum=np.float64(flat.sum()), sumsq=np.float64((flat * flat).sum()),
+                samples=flat[idx].astype(np.float32), numel=np.int64(flat.size))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote {} ({:.1f} KB)".format(path, os.path.getsize(path) / 1024))
+
+
+def flat_summary(prefix, t):
+    s = summarise(t)
+    return {prefix + "_" + k: v for k, v in s.items()}
+
+
+def hook_outputs(model, names):
+    """Forward hooks on named children -> dict name -> output tensor."""
+    store, handles = {}, []
+    mods = dict(model.named_modules())
+    for n in names:
+        handles.append(mods[n].register_forward_hook(
+            lambda m, i, o, n=n: store.__setitem__(n, o.detach().clone())))
+    return store, handles
+
+
+def require_equal(a, b, what):
+    if a.is_complex():
+        a, b = torch.view_as_real(a), torch.view_as_real(b)
+    if not torch.equal(a, b):
+        raise SystemExit("ORACLE != REFERENCE for {}: max abs diff {}".format(
+            what, (a - b).abs().max().item()))
+    print("  bit-exact: {}".format(what))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--check-only", action="store_true")
+    args = ap.parse_args()
+    sys.path.insert(0, args.reference)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    import UNet as R_UNet
+    import UNet_m as R_m
+    import cRFUNet as R_crf
+    import ResUNet as R_res
+    import DSUNet as R_ds
+    R_UNet.print_shape = False
+    out = {} if not args.check_only else None
+
+    # ---------------------------------------------------------------- UNet, narrow
+    print("UNet (table T1, f_dim=8, c_in=2, c_last=1), B=1 F=257 T=29")
+    enc_rows, dec_rows = unet20_layers(c_in=2, c_last=1, f_dim=8)
+    ref = R_UNet.UNet([R_m.Encoder(*r["args"], **r["kw"]) for r in enc_rows],
+                      [R_m.Decoder(*r["args"], **r["kw"]) for r in dec_rows])
+    seeded_fill_(ref, seed=11)
+    mine = oracle.UNet(*oracle.default_unet(c_in=2, c_last=1, f_dim=8))
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+    x = normal("unet_narrow/x", (1, 2, 257, 29), seed=11)
+    ref.eval(), mine.eval()
+    layer_names = ["encoder_{}".format(i) for i in range(10)] + \
+                  ["decoder_{}".format(i) for i in range(10)]
+    store, handles = hook_outputs(ref, layer_names)
+    with torch.no_grad():
+        y_ref, y_mine = ref(x), mine(x)
+    for h in handles:
+        h.remove()
+    require_equal(y_ref, y_mine, "UNet narrow eval")
+    if out is not None:
+        arrays = dict(out=y_ref.numpy())
+        arrays["layer_sum"] = np.array([store[n].double().sum().item() for n in layer_names])
+        arrays["layer_sumsq"] = np.array([(store[n].double() ** 2).sum().item() for n in layer_names])
+        save("unet_narrow_eval", **arrays)
+
+    # training step on the same narrow model (defined by this project: MSE to a
+    # seeded target, Adam defaults; the reference has no loss/optimizer)
+    print("UNet narrow: train-mode step (fwd, MSE, bwd, Adam)")
+    xb = normal("unet_narrow/xb", (2, 2, 257, 29), seed=12)
+    target = uniform("unet_narrow/target", (2, 1, 257, 29), 0.0, 1.0, seed=12)
+    results = []
+    for net in (ref, mine):
+        net.train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        opt.zero_grad()
+        loss = torch.mean((net(xb) - target) ** 2)
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        opt.step()
+        results.append((loss.detach().clone(), grads,
+                        {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    require_equal(results[0][0], results[1][0], "UNet narrow train loss")
+    for k in results[0][1]:
+        require_equal(results[0][1][k], results[1][1][k], "grad " + k)
+    for k in results[0][2]:
+        require_equal(results[0][2][k].float(), results[1][2][k].float(), "post-step " + k)
+    if out is not None:
+        arrays = dict(loss=results[0][0].numpy())
+        for k, g in results[0][1].items():
+            arrays["grad/" + k] = g.reshape(-1)[sample_index(g.numel(), 8)].numpy()
+            arrays["gradsum/" + k] = np.float64(g.double().sum().item())
+        for k, v in results[0][2].items():
+            v = v.float()
+            arrays["post/" + k] = v.reshape(-1)[sample_index(v.numel(), 8)].numpy()
+        save("unet_narrow_trainstep", **arrays)
+
+    # ---------------------------------------------------------------- UNet20
+    for T in (29, 125):
+        print("cRFUNet.UNet20 as shipped (f_dim=32, c_in=14), B=1 F=257 T={}".format(T))
+        ref = R_crf.UNet20()
+        seeded_fill_(ref, seed=21)
+        mine = oracle.UNet20()
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+        ref.T = mine.T = T
+        x = uniform("unet20/x{}".format(T), (1, 14, 257, T), 0.0, 1.0, seed=21)
+        ref.eval(), mine.eval()
+        with torch.no_grad():
+            y_ref, y_mine = ref(x), mine(x)
+        require_equal(y_ref, y_mine, "UNet20 eval T={}".format(T))
+        assert tuple(y_ref.shape) == (1, 4, 4, 1, 1, 257, T)
+        if out is not None:
+            save("unet20_eval_T{}".format(T), **flat_summary("out", y_ref))
+
+    # ---------------------------------------------------------------- ResUNet
+    print("ResUNet as shipped, B=1 F=257 T=16")
+    ref = R_res.ResUNet()
+    seeded_fill_(ref, seed=31)
+    mine = oracle.ResUNet()
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+    x = normal("resunet/x", (1, 4, 257, 16), seed=31)
+    ref.eval(), mine.eval()
+    with torch.no_grad():
+        y_ref, y_mine = ref(x), mine(x)
+    require_equal(y_ref, y_mine, "ResUNet eval")
+    if out is not None:
+        save("resunet_eval", out=y_ref.numpy())
+
+    print("UNet_m.ResBlock(16), B=2 F=9 T=40 (eval and train)")
+    ref = R_m.ResBlock(16)
+    seeded_fill_(ref, seed=32)
+    mine = oracle.ResBlock(16)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    x = normal("resblock/x", (2, 16, 9, 40), seed=32)
+    ref.eval(), mine.eval()
+    with torch.no_grad():
+        y_ref, y_mine = ref(x), mine(x)
+    require_equal(y_ref, y_mine, "ResBlock eval")
+    if out is not None:
+        save("resblock_eval", out=y_ref.numpy())
+
+    # ---------------------------------------------------------------- DSUNet
+    print("DSUNet with the UDSS.set_size table (mc=45, 8 in), B=2 F=257 T=16")
+    arch = dsunet_architecture(45, 8)
+    ref = R_ds.DSUNet(arch)
+    seeded_fill_(ref, seed=41)
+    mine = oracle.DSUNet(arch)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    assert sorted(ref.state_dict().keys()) == sorted(mine.state_dict().keys())
+    sf = normal("dsunet/sf", (2, 8, 257, 16), seed=41)
+    SV = normal("dsunet/SV", (2, 4, 514), seed=41)
+    ang = uniform("dsunet/theta", (2,), 0.0, 2 * np.pi, seed=41)
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    ref.eval(), mine.eval()
+    with torch.no_grad():
+        y_ref, y_mine = ref(sf, SV, theta), mine(sf, SV, theta)
+    require_equal(y_ref, y_mine, "DSUNet eval")
+    assert tuple(y_ref.shape) == (2, 257, 16) and y_ref.dtype == torch.complex64
+    X = torch.complex(normal("dsunet/Xr", (2, 257, 16), seed=41),
+                      normal("dsunet/Xi", (2, 257, 16), seed=41))
+    require_equal(ref.masking(X, y_ref), oracle.crm_apply(X, y_mine), "CRM.output")
+    if out is not None:
+        save("dsunet_eval", out=torch.view_as_real(y_ref).numpy(),
+             masked=torch.view_as_real(ref.masking(X, y_ref)).numpy())
+
+    # ------------------------------------------------- negative behaviours (kept as facts)
+    print("negative behaviours of the reference")
+    facts = {}
+    del R_UNet.print_shape
+    try:
+        R_UNet.UNet([], [])
+        facts["UNet_without_global"] = "ok"
+    except NameError:
+        facts["UNet_without_global"] = "NameError"
+    try:
+        R_crf.UNet10()
+        facts["UNet10"] = "ok"
+    except TypeError:
+        facts["UNet10"] = "TypeError"
+    try:
+        R_m.ResBlock(8, activation="GELU")
+        facts["ResBlock_GELU"] = "ok"
+    except Exception as e:  # noqa: BLE001
+        facts["ResBlock_GELU"] = type(e).__name__
+    print("  ", facts)
+    assert facts["UNet_without_global"] == "NameError" and facts["UNet10"] == "TypeError"
+    print("all oracle-vs-reference checks passed")
+
+
+if __name__ == "__main__":
+    main()
