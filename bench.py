@@ -1,0 +1,181 @@
+"""Headline benchmark: audio-seconds processed per second, UNet forward fp32.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (N > 1: launched by torch.distributed.run, one rank per
+GPU over RCCL).  A step = one forward of the "UNet default config" (the 10+10
+layer table of cRFUNet.py:192-218 with c_in=2 and a 1-channel last decoder
+around UNet.py's shell) over a batch of 64 synthetic 4-second utterances per
+GPU: complex STFT planes N(0,1), n_fft 512 / hop 128 -> F=257, T=501, zero
+padded to T=509 (the table only accepts T = 13 mod 16); an utterance counts
+4.0 s.  Inputs are resident in HBM before the timed region.  The batch shards
+over ranks with no collective in the data path (eval-mode forward has no
+cross-sample op); a barrier brackets the timed region and the maximum time
+over ranks is used.
+
+Rank 0 prints ONE JSON line.  "roofline" is for the dominant kernel
+(conv_mfma_kernel<1,4,2,2>: every plain conv and the stride-(s,1) transposed
+convs), from HIP events recorded on the launch stream around each of its
+launches inside the timed region: algorithmic FLOPs (2 x MACs of the layer)
+/ launch time, against the dense fp32 MFMA peak.  "cpu_baseline" times the
+CPU oracle (this repository's restatement of the reference, stock torch CPU
+ops) on a batch of 4 on the host cores, rank 0 at N=1 only.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 64
+AUDIO_SECONDS = 4.0
+F_BINS, T_FRAMES, T_PADDED = 257, 501, 509
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def synthetic_batch(batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((batch, 2, F_BINS, T_FRAMES), generator=g)
+    return torch.nn.functional.pad(x, (0, T_PADDED - T_FRAMES)).contiguous()
+
+
+def conv_macs(d):
+    """Multiply-accumulates of one fused conv launch (ConvDesc)."""
+    cin = d.C0 + (d.C1 if d.in_mode == 1 else 0)
+    if d.transposed:
+        return d.N * d.H * d.W * cin * d.K * d.kh * d.kw
+    return d.N * d.OH * d.OW * d.K * cin * d.kh * d.kw
+
+
+def kernel_variant(d):
+    """Which conv_mfma_kernel instantiation serves this layer."""
+    ng = d.sw if d.transposed else 1
+    wn = 1 if d.K <= 32 else 2
+    return "conv_mfma_kernel<{},{},{},{}>".format(ng, 4 // ng, 4 // wn, wn)
+
+
+def cpu_baseline(threads):
+    import oracle
+    from unet_amd import seeded_fill_
+    torch.set_num_threads(threads)
+    net = oracle.UNet(*oracle.default_unet(c_in=2, c_last=1, f_dim=32)).eval()
+    seeded_fill_(net, seed=0)
+    x = synthetic_batch(4, 1234)
+    best = float("inf")
+    with torch.no_grad():
+        for i in range(2 + 5):
+            t0 = time.perf_counter()
+            net(x)
+            dt = time.perf_counter() - t0
+            if i >= 2:
+                best = min(best, dt)
+    return dict(value=4 * AUDIO_SECONDS / best, unit="audio-s/s", cores=threads, kind="port",
+                sample="oracle UNet (same table and weights) forward, batch 4 x [2,257,509] fp32, "
+                       "best of 5 after 2 warm-ups, torch {} CPU".format(torch.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus {} but WORLD_SIZE={}: launch with torch.distributed.run "
+                         "--nproc-per-node {}".format(args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import unet_amd
+    from unet_amd import ops
+
+    net = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=32))
+    unet_amd.seeded_fill_(net, seed=0)       # every rank regenerates the same weights
+    net.eval().to(dev)
+    x = synthetic_batch(PER_GPU_BATCH, 1234 + rank).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = net(x)
+        torch.cuda.synchronize()
+
+        records = []
+        ops.set_launch_observer(lambda name, d, e0, e1: records.append(
+            (kernel_variant(d), conv_macs(d), e0, e1)))
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = net(x)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ops.set_launch_observer(None)
+    assert tuple(y.shape) == (PER_GPU_BATCH, 1, F_BINS, T_PADDED)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        per_variant = {}
+        for variant, macs, e0, e1 in records:
+            acc = per_variant.setdefault(variant, [0.0, 0.0, 0])
+            acc[0] += 2.0 * macs
+            acc[1] += e0.elapsed_time(e1) * 1e-3
+            acc[2] += 1
+        dominant = max(per_variant, key=lambda k: per_variant[k][1])
+        flops, secs, launches = per_variant[dominant]
+        achieved = flops / secs / 1e12
+        result = {
+            "metric": "audio-seconds processed/sec (whole node), UNet fwd fp32",
+            "value": world * PER_GPU_BATCH * AUDIO_SECONDS * args.steps / elapsed,
+            "unit": "audio-s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "UNet default config (cRFUNet.UNet20 layer table, c_in=2, c_last=1) "
+                                   "eval forward, batch 64 x [2,257,509] fp32 per GPU "
+                                   "(4 s @ 16 kHz, n_fft 512, hop 128, T 501 zero-padded to 509)",
+                       "per_gpu_batch": PER_GPU_BATCH, "global_batch": world * PER_GPU_BATCH,
+                       "gflop_per_utterance": 64.34, "parallelism": "batch-sharded x{}".format(world)},
+            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": launches, "avg_launch_ms": 1e3 * secs / launches,
+                         "gflop_per_launch": flops / launches / 1e9,
+                         "all_kernels": {k: {"tflops": v[0] / v[1] / 1e12, "ms": 1e3 * v[1] / args.steps,
+                                             "launches_per_step": v[2] // args.steps}
+                                         for k, v in per_variant.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(torch.get_num_threads())
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/*
+ * unetmi.h -- C ABI of libunetmi.so, the MI355X (gfx950) op library behind the
+ * U-Net family's forward pass.
+ *
+ * Every entry point takes plain device/host pointers and sizes (no torch
+ * types), enqueues on the caller's HIP stream, never synchronises the device
+ * and never allocates device memory: activations, packed weights and
+ * workspaces are owned by the caller.  Return value 0 = success, negative =
+ * UNETMI_E_* ; unetmi_last_error() gives the message of the calling thread's
+ * last failure.  All tensors are fp32, NCHW contiguous, [B, C, F, T] with the
+ * time axis innermost -- the layout of the reference's modules
+ * (UNet.py:75, cRFUNet.py:280, ResUNet.py:162).
+ *
+ * Each function names the reference call sites it replaces.  The reference has
+ * no native interface of its own (it is pure torch.nn); the Python host side
+ * in unet_amd/ binds these symbols with ctypes and registers them as
+ * torch.library ops.
+ */
+#ifndef UNETMI_H
+#define UNETMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNETMI_VERSION 100
+
+enum {
+    UNETMI_OK = 0,
+    UNETMI_E_BAD_DESC = -1,     /* inconsistent or unsupported geometry      */
+    UNETMI_E_BAD_ARG = -2,      /* null pointer / size mismatch              */
+    UNETMI_E_HIP = -3,          /* a HIP runtime call failed                 */
+    UNETMI_E_UNSUPPORTED = -4   /* valid request this build cannot serve     */
+};
+
+/* Epilogue activations (the reference's string switch, UNet_m.py:324-337,
+ * plus the heads' Sigmoid / Softplus / Tanh: UNet.py:72, cRFUNet.py:269-272,
+ * ResUNet.py:144, DSUNet.py:356). */
+enum {
+    UNETMI_ACT_NONE = 0,
+    UNETMI_ACT_LEAKY = 1,    /* x>=0 ? x : slope*x ; slope = act_param[0] (LeakyReLU 0.01) or
+                                act_param[c] (PReLU, see act_param_per_channel) */
+    UNETMI_ACT_RELU = 2,
+    UNETMI_ACT_SILU = 3,
+    UNETMI_ACT_SOFTPLUS = 4, /* beta 1, threshold 20 */
+    UNETMI_ACT_SIGMOID = 5,
+    UNETMI_ACT_TANH = 6,
+    UNETMI_ACT_GELU = 7      /* erf form */
+};
+
+/* How the second input tensor combines with the first. */
+enum {
+    UNETMI_IN_SINGLE = 0,
+    UNETMI_IN_CONCAT = 1,    /* channels [0,C0) from in0, [C0,C0+C1) from in1: torch.cat([p, skip], 1)
+                                fused into the read (UNet.py:106, cRFUNet.py:311, DSUNet.py:622) */
+    UNETMI_IN_ADD = 2        /* in0 + in1 elementwise, C1 == C0: torch.add(y, res) fused into the
+                                read (ResUNet.py:209) */
+};
+
+/* Geometry + epilogue of one fused convolution layer.
+ *
+ * transposed = 0: nn.Conv2d; weight [K, (C0+C1)/groups, kh, kw].
+ * transposed = 1: nn.ConvTranspose2d; weight [C0+C1, K, kh, kw]; stride > 1
+ *                 requires dilation 1 on that axis.
+ * groups is 1 (dense) for this entry point.
+ * Epilogue, per output element v = acc + bias[k]:
+ *   act_first = 0:  v = act(v * scale[k] + shift[k])      (conv -> BN -> act:  UNet_m.py:340-345, :379-383)
+ *   act_first = 1:  v = act(v) * scale[k] + shift[k]      (conv -> act -> BN:  UNet_m.py:549-552)
+ *   then v *= gate[n*K + k] if has_gate                    (DSUNet.py:599-602)
+ *   then v += residual[n,k,oh,ow] if has_residual          (UNet_m.py:561)
+ * scale/shift are eval-mode BatchNorm folded by the caller:
+ *   scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale.
+ */
+typedef struct UnetmiConvDesc {
+    int32_t N;               /* batch                                        */
+    int32_t C0, C1;          /* channels of in0 and in1 (C1 = 0 if single)   */
+    int32_t H, W;            /* input  F, T                                  */
+    int32_t K;               /* output channels                              */
+    int32_t OH, OW;          /* output F, T (must equal the torch formula)   */
+    int32_t kh, kw;
+    int32_t sh, sw;
+    int32_t ph, pw;
+    int32_t dh, dw;
+    int32_t oph, opw;        /* output_padding (transposed only)             */
+    int32_t transposed;
+    int32_t in_mode;         /* UNETMI_IN_*                                  */
+    int32_t act;             /* UNETMI_ACT_*                                 */
+    int32_t act_first;
+    int32_t act_param_per_channel; /* 1: act_param has K entries, 0: one     */
+    int32_t has_gate;
+    int32_t has_residual;
+    int32_t reserved[3];
+} UnetmiConvDesc;
+
+int unetmi_version(void);
+
+/* Copies the calling thread's last error message (NUL-terminated) into buf. */
+void unetmi_last_error(char* buf, size_t n);
+
+/* Bytes of the packed-weight image unetmi_conv2d_fwd expects for this layer
+ * (0 on a bad descriptor).  The image depends on geometry only, not on N. */
+size_t unetmi_conv2d_packed_weight_bytes(const UnetmiConvDesc* d);
+
+/* HOST function: rearranges a torch-layout weight tensor (host pointer,
+ * contiguous fp32, [K,C,kh,kw] or [C,K,kh,kw] for transposed) into the
+ * per-phase / per-channel-chunk image the kernel streams through LDS
+ * (host pointer, unetmi_conv2d_packed_weight_bytes() bytes).  Called once per
+ * layer when parameters change; the caller uploads the image. */
+int unetmi_conv2d_pack_weights(const UnetmiConvDesc* d, const float* w, float* packed);
+
+/* Fused convolution layer on the device.  Replaces, in one launch,
+ *   Encoder.forward  conv -> dropout(p=0) -> bn -> acti       UNet_m.py:340-345
+ *   Decoder.forward  transconv -> bn -> acti                  UNet_m.py:379-383
+ *   the torch.cat feeding each decoder                        UNet.py:106
+ *   the 1x1 heads (linear + Sigmoid / Softplus)               UNet.py:110-111, cRFUNet.py:315-316
+ *   ResUNet's res_path 1x1 blocks and y + res                 ResUNet.py:125-132, :209
+ *   DSUNet's per-(batch,channel) gate                         DSUNet.py:599-602
+ * in0/in1/out/residual: device fp32 NCHW; wpacked: device image from
+ * unetmi_conv2d_pack_weights; bias/scale/shift: device fp32 [K];
+ * act_param: device fp32 [1] or [K] (may be null for activations without a
+ * parameter); gate: device fp32 [N*K] or null; residual: device fp32 shaped
+ * like out, or null.  stream: hipStream_t passed as void*. */
+int unetmi_conv2d_fwd(const UnetmiConvDesc* d,
+                      const float* in0, const float* in1,
+                      const float* wpacked,
+                      const float* bias, const float* scale, const float* shift,
+                      const float* act_param, const float* gate,
+                      const float* residual,
+                      float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNETMI_H */

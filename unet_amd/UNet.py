@@ -1,0 +1,106 @@
+"""Device ``UNet`` with the reference's constructor and ``forward`` (UNet.py:6-113).
+
+The concat-skip shell is the reference's; what changes is that a decoder built
+from ``unet_amd.UNet_m.Decoder`` receives its skip tensor as a second kernel
+input (no ``torch.cat``), and the 1x1 ``linear`` + Sigmoid head is one fused
+launch.  Blocks of any other type are called as the reference calls them.
+"""
+
+import torch
+import torch.nn as nn
+
+from .UNet_m import Decoder, Encoder
+from .fused import FusedConv, require_device_tensor
+
+
+def register_concat_shell(net, encoders, decoders, bottlenecks, res_paths):
+    """Submodule registration common to UNet and cRFUNet.UNet20: names
+    ``encoder_i`` / ``decoder_i`` / ``res_path{i}`` / ``bottleneck{i}``
+    (UNet.py:28-66, cRFUNet.py:229-267).  The res-path list has one trailing
+    identity whose output is never consumed."""
+    n = len(encoders)
+    net.len_model = n
+    net.encoders, net.decoders = encoders, decoders
+    for i, m in enumerate(encoders):
+        net.add_module("encoder_{}".format(i), m)
+    for i, m in enumerate(decoders):
+        net.add_module("decoder_{}".format(i), m)
+    if res_paths is not None:
+        if len(res_paths) != n - 1:
+            raise Exception("ERROR::unmatched res_path : {} != {}".format(len(res_paths), n - 1))
+        paths = list(res_paths)
+    else:
+        paths = [nn.Identity() for _ in range(n - 1)]
+    paths.append(nn.Identity())
+    net.res_paths = paths
+    for i, m in enumerate(paths):
+        net.add_module("res_path{}".format(i), m)
+    net.bottlenecks = list(bottlenecks) if bottlenecks is not None else [nn.Identity()]
+    for i, m in enumerate(net.bottlenecks):
+        net.add_module("bottleneck{}".format(i), m)
+
+
+def concat_shell_forward(net, x):
+    """Encoders, bottleneck, decoders with [decoder output, skip] channel order
+    (UNet.py:85-106).  Returns the last decoder's output."""
+    skips = []
+    for i, enc in enumerate(net.encoders):
+        skips.append(net.res_paths[i](x))
+        x = enc(x)
+        if net.print_shape:
+            print("Encoder {} : {}".format(i, x.shape))
+    p = x
+    for i, b in enumerate(net.bottlenecks):
+        p = b(p)
+        if net.print_shape:
+            print("bottleneck {} : {}".format(i, p.shape))
+    last = net.len_model - 1
+    skip = None
+    for i, dec in enumerate(net.decoders):
+        if skip is None:
+            p = dec(p)
+        elif isinstance(dec, Decoder):
+            p = dec(p, skip)                      # concat fused into the kernel's read
+        else:
+            p = dec(torch.cat([p, skip], dim=1))
+        if net.print_shape:
+            print("Decoder {} : {}".format(i, p.shape))
+        if i == last:
+            break
+        skip = skips[last - i]
+    return p
+
+
+class UNet(nn.Module):
+    """Drop-in for the reference ``UNet``.  ``print_shape`` is a keyword here; the
+    reference reads an undefined global of that name (UNet.py:24)."""
+
+    def __init__(self, encoders, decoders, bottlenecks=None, res_paths=None, device="cuda:0",
+                 print_shape=False):
+        super().__init__()
+        self.device = device
+        if len(encoders) != len(decoders):
+            raise Exception("ERROR::unmatched legnth : enc {} != dec {}".format(
+                len(encoders), len(decoders)))
+        self.print_shape = print_shape
+        register_concat_shell(self, encoders, decoders, bottlenecks, res_paths)
+        self.add_module("linear", nn.Conv2d(1, 1, 1))
+        self.activation_mask = nn.Sigmoid()
+        self._head = None
+
+    def forward(self, x):
+        require_device_tensor(x, "UNet")
+        p = concat_shell_forward(self, x)
+        if self._head is None:
+            object.__setattr__(self, "_head", FusedConv(self.linear, None, self.activation_mask))
+        return self._head(p)
+
+
+def default_unet_blocks(c_in=2, c_last=1, f_dim=32):
+    """(encoders, decoders) of the "UNet default config": the 10+10 layer table
+    that cRFUNet.py:192-218 inlines, with c_in input channels and a c_last-channel
+    last decoder (UNet.py's head is Conv2d(1,1,1), so c_last = 1)."""
+    from .tables import unet20_layers
+    enc_rows, dec_rows = unet20_layers(c_in=c_in, c_last=c_last, f_dim=f_dim)
+    return ([Encoder(*r["args"], **r["kw"]) for r in enc_rows],
+            [Decoder(*r["args"], **r["kw"]) for r in dec_rows])

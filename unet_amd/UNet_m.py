@@ -1,0 +1,116 @@
+"""Device building blocks with the reference's constructors (UNet_m.py).
+
+``Encoder`` / ``Decoder`` keep the reference's submodule names (``conv`` /
+``transconv``, ``bn``, ``acti``, ``dropout``) so checkpoints load unchanged; their
+``forward`` is one fused HIP launch (conv or transposed conv, eval-BatchNorm
+affine and activation in the epilogue).  ``Decoder.forward`` additionally
+accepts the skip tensor, read as extra input channels inside the kernel
+instead of through ``torch.cat``.
+"""
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .fused import FusedConv, require_device_tensor
+
+
+def _activation(name, where):
+    # same switch and message as UNet_m.py:324-337
+    if name == "LeakyReLU":
+        return nn.LeakyReLU(inplace=True)
+    if name == "SiLU":
+        return nn.SiLU(inplace=True)
+    if name == "Softplus":
+        return nn.Softplus()
+    if name == "PReLU":
+        return nn.PReLU()
+    if name == "ReLU":
+        return nn.ReLU()
+    if name == "GELU":
+        return nn.GELU()
+    raise Exception("ERROR::{}:Unknown activation type {}".format(where, name))
+
+
+def _norm(name):
+    # UNet_m.py:312-319
+    if name == "BatchNorm2d":
+        return nn.BatchNorm2d
+    if name == "InstanceNorm2d":
+        return nn.InstanceNorm2d
+    if name == "LayerNorm":
+        return nn.LayerNorm
+    raise Exception("ERROR::Encoder: unknown normalization - {}".format(name))
+
+
+class _FusedBlock(nn.Module):
+    """Shared forward of Encoder / Decoder: fused when the norm is an eval-mode
+    BatchNorm2d and the activation is one the epilogue implements; otherwise
+    the HIP convolution followed by torch's norm/activation on the device."""
+
+    def _setup(self, conv_attr):
+        self._conv_attr = conv_attr
+        self._fused = None
+
+    def _layer(self):
+        if self._fused is None:
+            object.__setattr__(self, "_fused",
+                               FusedConv(getattr(self, self._conv_attr), self.bn, self.acti))
+        return self._fused
+
+    def _run(self, x, skip=None, in_mode=None, gate=None):
+        require_device_tensor(x, type(self).__name__)
+        if self.training:
+            raise NotImplementedError(
+                "{}: train-mode forward (batch statistics) is not available in this build; "
+                "call .eval()".format(type(self).__name__))
+        layer = self._layer()
+        if layer.fusable():
+            return layer(x, skip, in_mode=in_mode, gate=gate)
+        y = layer(x, skip, in_mode=in_mode, epilogue=False)
+        y = self.acti(self.bn(y))
+        if gate is not None:
+            y = y * gate[:, :, None, None]
+        return y
+
+
+class Encoder(_FusedBlock):
+    """Conv2d -> Dropout -> norm -> activation (UNet_m.py:304-345)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding=None, dilation=1,
+                 norm="BatchNorm2d", padding_mode="zeros", dropout=0.0, activation="LeakyReLU"):
+        super().__init__()
+        if padding is None:
+            padding = [(k - 1) // 2 for k in kernel_size]
+        norm_cls = _norm(norm)
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                              padding=padding, dilation=dilation, padding_mode=padding_mode)
+        self.bn = norm_cls(out_channels)
+        self.acti = _activation(activation, "Encoder")
+        self.dropout = nn.Dropout(dropout)
+        self._setup("conv")
+
+    def forward(self, x, gate=None):
+        return self._run(x, gate=gate)
+
+
+class Decoder(_FusedBlock):
+    """ConvTranspose2d -> norm -> activation (UNet_m.py:347-383).
+
+    ``forward(x, skip)`` computes ``decoder(torch.cat([x, skip], 1))`` without
+    forming the concatenation; ``forward(x, skip, add=True)`` computes
+    ``decoder(x + skip)``."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding=(0, 0), dilation=1,
+                 output_padding=(0, 0), activation="LeakyReLU", norm="BatchNorm2d"):
+        super().__init__()
+        norm_cls = _norm(norm)
+        self.transconv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size,
+                                            stride=stride, dilation=dilation,
+                                            output_padding=output_padding, padding=padding)
+        self.bn = norm_cls(out_channels)
+        self.acti = _activation(activation, "Encoder")
+        self._setup("transconv")
+
+    def forward(self, x, skip=None, add=False):
+        return self._run(x, skip, in_mode=(_lib.IN_ADD if add else None) if skip is not None else None)

@@ -1,0 +1,14 @@
+"""unet_amd -- MI355X-native forward path of the kooBH/UNet model family.
+
+Drop-in ``nn.Module`` classes with the reference's constructors and ``forward``
+signatures whose device path is hand-written HIP (libunetmi.so) bound through
+``torch.library``.  Importing the package loads the shared library and fails
+loudly when it is missing: there is no CPU or eager fallback.
+"""
+
+from . import _lib, ops  # noqa: F401  (loads libunetmi.so, registers torch.ops.unetmi.*)
+from .UNet_m import Encoder, Decoder
+from .UNet import UNet, default_unet_blocks
+from .seeding import seeded_fill_
+
+__all__ = ["Encoder", "Decoder", "UNet", "default_unet_blocks", "seeded_fill_"]

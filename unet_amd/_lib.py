@@ -1,0 +1,72 @@
+"""ctypes binding of libunetmi.so (C ABI declared in include/unetmi.h).
+
+The library is the only compute path of this package: importing this module
+fails loudly when the shared object is missing or does not export a symbol
+the header declares.  There is no CPU or eager fallback.
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunetmi.so")
+
+# activation / input-mode codes of include/unetmi.h
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SILU, ACT_SOFTPLUS, ACT_SIGMOID, ACT_TANH, ACT_GELU = range(8)
+IN_SINGLE, IN_CONCAT, IN_ADD = range(3)
+
+EXPORTED_SYMBOLS = (
+    "unetmi_version",
+    "unetmi_last_error",
+    "unetmi_conv2d_packed_weight_bytes",
+    "unetmi_conv2d_pack_weights",
+    "unetmi_conv2d_fwd",
+)
+
+
+class ConvDesc(ctypes.Structure):
+    """struct UnetmiConvDesc."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "N", "C0", "C1", "H", "W", "K", "OH", "OW", "kh", "kw", "sh", "sw", "ph", "pw",
+        "dh", "dw", "oph", "opw", "transposed", "in_mode", "act", "act_first",
+        "act_param_per_channel", "has_gate", "has_residual")] + [("reserved", ctypes.c_int32 * 3)]
+
+
+class UnetmiError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "unet_amd: {} is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C unet_amd/csrc`; there is no fallback path".format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for sym in EXPORTED_SYMBOLS:
+        if not hasattr(lib, sym):
+            raise ImportError("unet_amd: {} does not export {}".format(LIB_PATH, sym))
+    vp, fp = ctypes.c_void_p, ctypes.c_void_p
+    lib.unetmi_version.restype = ctypes.c_int
+    lib.unetmi_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    lib.unetmi_last_error.restype = None
+    lib.unetmi_conv2d_packed_weight_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+    lib.unetmi_conv2d_packed_weight_bytes.restype = ctypes.c_size_t
+    lib.unetmi_conv2d_pack_weights.argtypes = [ctypes.POINTER(ConvDesc), fp, fp]
+    lib.unetmi_conv2d_pack_weights.restype = ctypes.c_int
+    lib.unetmi_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 10 + [vp]
+    lib.unetmi_conv2d_fwd.restype = ctypes.c_int
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib.unetmi_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(code, what):
+    if code != 0:
+        raise UnetmiError("{} failed ({}): {}".format(what, code, last_error()))

@@ -1,0 +1,165 @@
+// Host-side plan of the implicit-GEMM convolution: how a (transposed)
+// convolution is cut into output phases, taps, channel chunks and workgroup
+// tiles.  Shared by the weight packer and the launcher so that the packed
+// image and the kernel's read order cannot drift apart.
+#pragma once
+
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../include/unetmi.h"
+
+namespace unetmi {
+
+constexpr int kMaxPhase = 4;      // output phases per axis = stride of a transposed conv
+constexpr int kWaves = 4;         // waves per workgroup
+constexpr int kTileJ = 32;        // output columns of one MFMA tile (the 32 of 32x32x2)
+constexpr int kLdsBudget = 64 * 1024;
+
+// One spatial axis.  Output index o = nphase * q + phase (q = "phase index").
+// Tap t of that phase reads input index  q * in_step + base[phase] + t * tap_step
+// and weight index  kidx0[phase] + t * kidx_step[phase].
+struct AxisPlan {
+    int nphase = 1;
+    int in_step = 1;
+    int tap_step = 1;
+    int ntap[kMaxPhase] = {0, 0, 0, 0};
+    int base[kMaxPhase] = {0, 0, 0, 0};
+    int kidx0[kMaxPhase] = {0, 0, 0, 0};
+    int kidx_step[kMaxPhase] = {1, 1, 1, 1};
+    int nout[kMaxPhase] = {0, 0, 0, 0};   // phase indices that land inside the output
+};
+
+inline bool plan_axis(bool transposed, int in, int out, int k, int s, int p, int d, int op,
+                      AxisPlan* ax, std::string* err) {
+    if (k < 1 || s < 1 || d < 1 || p < 0 || in < 1) { *err = "non-positive geometry"; return false; }
+    if (!transposed) {
+        const int expect = (in + 2 * p - d * (k - 1) - 1) / s + 1;
+        if (in + 2 * p - d * (k - 1) - 1 < 0 || out != expect) {
+            *err = "conv output size " + std::to_string(out) + " != " + std::to_string(expect);
+            return false;
+        }
+        ax->nphase = 1; ax->in_step = s; ax->tap_step = d;
+        ax->ntap[0] = k; ax->base[0] = -p; ax->kidx0[0] = 0; ax->kidx_step[0] = 1; ax->nout[0] = out;
+        return true;
+    }
+    const int expect = (in - 1) * s - 2 * p + d * (k - 1) + op + 1;
+    if (out != expect || out < 1) {
+        *err = "transposed conv output size " + std::to_string(out) + " != " + std::to_string(expect);
+        return false;
+    }
+    if (s > kMaxPhase) { *err = "transposed stride > 4"; return false; }
+    if (s > 1 && d != 1) { *err = "transposed conv with stride>1 needs dilation 1"; return false; }
+    ax->nphase = s; ax->in_step = 1; ax->tap_step = (s == 1) ? d : 1;
+    for (int a = 0; a < s; ++a) {
+        // o + p - kidx*d = i*s  ->  kidx = r (mod s) with r = (a + p) mod s   (d = 1 when s > 1)
+        const int r = (a + p) % s;
+        const int nt = (r < k) ? (k - r + s - 1) / s : 0;
+        ax->ntap[a] = nt;
+        // taps visited in increasing input index: t = 0 is the LARGEST weight index
+        ax->kidx0[a] = r + s * (nt - 1);
+        ax->kidx_step[a] = -s;
+        ax->base[a] = (a + p - r) / s - (nt - 1) * ax->tap_step;
+        ax->nout[a] = (a < out) ? (out - a + s - 1) / s : 0;
+    }
+    return true;
+}
+
+struct ConvPlan {
+    AxisPlan h, w;
+    int Ctot = 0;          // channels summed over (C0+C1 for concat, C0 otherwise)
+    int ci_chunk = 2;      // channels staged per LDS pass (even)
+    int nchunk = 1;
+    int NB = 64;           // output channels per workgroup (32 or 64)
+    int nco_blk = 1;
+    int WM = 2, WN = 2;    // wave grid inside the workgroup (WM*WN = 4)
+    int NG = 1, TPG = 4;   // per wave: NG column-phase groups x TPG rows = 4 MFMA tiles
+    int TI = 8;            // phase-index rows per workgroup = WM * TPG
+    int nrows = 1, ncols = 1, pitch = 1, plane = 1;   // LDS input tile (floats)
+    int w_colmin = 0;      // smallest column offset over the column phases
+    int wtaps[kMaxPhase] = {0, 0, 0, 0};      // tap instances per channel pair, per row phase
+    size_t w_phase_off[kMaxPhase] = {0, 0, 0, 0};   // float offset of each row phase's image
+    size_t packed_floats = 0;
+    int in_tile_floats = 0, w_tile_floats = 0;
+    size_t lds_bytes = 0;
+    int nit[kMaxPhase] = {0, 0, 0, 0};        // row tiles per row phase
+    int njt = 1;                               // column tiles
+};
+
+inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
+    if (d.N < 0 || d.C0 < 1 || d.C1 < 0 || d.K < 1) { *err = "bad channel/batch counts"; return false; }
+    if (d.in_mode == UNETMI_IN_SINGLE && d.C1 != 0) { *err = "C1 must be 0 for a single input"; return false; }
+    if (d.in_mode == UNETMI_IN_ADD && d.C1 != d.C0) { *err = "add mode needs C1 == C0"; return false; }
+    if (d.in_mode == UNETMI_IN_CONCAT && d.C1 < 1) { *err = "concat mode needs C1 > 0"; return false; }
+    if (d.in_mode < 0 || d.in_mode > 2) { *err = "unknown in_mode"; return false; }
+    if (d.act < 0 || d.act > UNETMI_ACT_GELU) { *err = "unknown activation"; return false; }
+    if (!d.transposed && (d.oph || d.opw)) { *err = "output_padding on a plain conv"; return false; }
+    if (!plan_axis(d.transposed, d.H, d.OH, d.kh, d.sh, d.ph, d.dh, d.oph, &pl->h, err)) return false;
+    if (!plan_axis(d.transposed, d.W, d.OW, d.kw, d.sw, d.pw, d.dw, d.opw, &pl->w, err)) return false;
+    if (pl->w.nphase != 1 && pl->w.nphase != 2) { *err = "column stride of a transposed conv must be 1 or 2"; return false; }
+
+    pl->Ctot = (d.in_mode == UNETMI_IN_CONCAT) ? d.C0 + d.C1 : d.C0;
+    pl->NB = (d.K <= 32) ? 32 : 64;
+    pl->nco_blk = (d.K + pl->NB - 1) / pl->NB;
+    pl->WN = pl->NB / 32; pl->WM = kWaves / pl->WN;
+    pl->NG = pl->w.nphase; pl->TPG = 4 / pl->NG;
+    pl->TI = pl->WM * pl->TPG;
+
+    int max_nth = 0;
+    for (int a = 0; a < pl->h.nphase; ++a) max_nth = std::max(max_nth, pl->h.ntap[a]);
+    pl->nrows = (pl->TI - 1) * pl->h.in_step + std::max(max_nth - 1, 0) * pl->h.tap_step + 1;
+    int cmin = 1 << 30, cmax = -(1 << 30), sum_ntw = 0;
+    for (int g = 0; g < pl->w.nphase; ++g) {
+        sum_ntw += pl->w.ntap[g];
+        if (pl->w.ntap[g] == 0) continue;
+        cmin = std::min(cmin, pl->w.base[g]);
+        cmax = std::max(cmax, pl->w.base[g] + (pl->w.ntap[g] - 1) * pl->w.tap_step);
+    }
+    if (cmin > cmax) { cmin = 0; cmax = 0; }
+    pl->w_colmin = cmin;
+    pl->ncols = (kTileJ - 1) * pl->w.in_step + (cmax - cmin) + 1;
+    pl->pitch = pl->ncols | 1;                      // odd pitch: rows start on different banks
+    pl->plane = pl->nrows * pl->pitch;
+
+    int max_wtaps = 0;
+    for (int a = 0; a < pl->h.nphase; ++a) {
+        pl->wtaps[a] = pl->h.ntap[a] * sum_ntw;
+        max_wtaps = std::max(max_wtaps, pl->wtaps[a]);
+    }
+    // channels per LDS pass: the most that fits next to their weights
+    const int cpad = (pl->Ctot + 1) & ~1;
+    const size_t per_pair = (size_t)2 * pl->plane * 4 + (size_t)max_wtaps * 2 * pl->NB * 4;
+    int max_pairs = (int)std::min<size_t>((size_t)kLdsBudget / std::max<size_t>(per_pair, 1), 16);
+    max_pairs = std::min(max_pairs, cpad / 2);
+    if (max_pairs < 1) { *err = "one channel pair does not fit in LDS for this geometry"; return false; }
+    // among chunk sizes in (max/2, max], take the one that pads the channel
+    // count the least (padding is MFMA work on zeros); ties go to the larger
+    int pairs = max_pairs, best_total = 1 << 30;
+    for (int p = max_pairs; p >= std::max(1, max_pairs / 2 + 1); --p) {
+        const int total = ((cpad / 2 + p - 1) / p) * p;
+        if (total < best_total) { best_total = total; pairs = p; }
+    }
+    const int nchunk = (cpad / 2 + pairs - 1) / pairs;
+    pl->ci_chunk = 2 * pairs;
+    pl->nchunk = nchunk;
+
+    size_t off = 0;
+    for (int a = 0; a < pl->h.nphase; ++a) {
+        pl->w_phase_off[a] = off;
+        off += (size_t)pl->nco_blk * pl->nchunk * pairs * pl->wtaps[a] * 2 * pl->NB;
+    }
+    pl->packed_floats = std::max<size_t>(off, 4);
+    pl->in_tile_floats = (pl->ci_chunk * pl->plane + 3) & ~3;
+    pl->w_tile_floats = pairs * max_wtaps * 2 * pl->NB;
+    pl->lds_bytes = (size_t)(pl->in_tile_floats + pl->w_tile_floats) * 4;
+
+    int max_nj = 0;
+    for (int g = 0; g < pl->w.nphase; ++g) max_nj = std::max(max_nj, pl->w.nout[g]);
+    pl->njt = (max_nj + kTileJ - 1) / kTileJ;
+    for (int a = 0; a < pl->h.nphase; ++a) pl->nit[a] = (pl->h.nout[a] + pl->TI - 1) / pl->TI;
+    return true;
+}
+
+}  // namespace unetmi

@@ -1,0 +1,102 @@
+// C ABI of libunetmi.so (declarations and contracts: include/unetmi.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "conv_plan.hpp"
+
+namespace unetmi {
+hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
+                            const float* in0, const float* in1, const float* wpacked,
+                            const float* bias, const float* scale, const float* shift,
+                            const float* act_param, const float* gate, const float* residual,
+                            float* out, hipStream_t stream);
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+}  // namespace unetmi
+
+using namespace unetmi;
+
+extern "C" {
+
+int unetmi_version(void) { return UNETMI_VERSION; }
+
+void unetmi_last_error(char* buf, size_t n) {
+    if (!buf || n == 0) return;
+    std::strncpy(buf, g_last_error.c_str(), n - 1);
+    buf[n - 1] = '\0';
+}
+
+size_t unetmi_conv2d_packed_weight_bytes(const UnetmiConvDesc* d) {
+    if (!d) { fail(UNETMI_E_BAD_ARG, "null descriptor"); return 0; }
+    ConvPlan pl;
+    std::string err;
+    if (!make_plan(*d, &pl, &err)) { fail(UNETMI_E_BAD_DESC, err); return 0; }
+    return pl.packed_floats * sizeof(float);
+}
+
+int unetmi_conv2d_pack_weights(const UnetmiConvDesc* d, const float* w, float* packed) {
+    if (!d || !w || !packed) return fail(UNETMI_E_BAD_ARG, "null argument to pack_weights");
+    ConvPlan pl;
+    std::string err;
+    if (!make_plan(*d, &pl, &err)) return fail(UNETMI_E_BAD_DESC, err);
+    std::memset(packed, 0, pl.packed_floats * sizeof(float));
+    const int cpc = pl.ci_chunk / 2;
+    const int C = pl.Ctot, K = d->K, KH = d->kh, KW = d->kw;
+    for (int a = 0; a < pl.h.nphase; ++a) {
+        float* dst = packed + pl.w_phase_off[a];
+        for (int cb = 0; cb < pl.nco_blk; ++cb)
+            for (int chunk = 0; chunk < pl.nchunk; ++chunk)
+                for (int cp = 0; cp < cpc; ++cp)
+                    for (int g = 0; g < pl.w.nphase; ++g)
+                        for (int th = 0; th < pl.h.ntap[a]; ++th)
+                            for (int tw = 0; tw < pl.w.ntap[g]; ++tw) {
+                                const int ky = pl.h.kidx0[a] + th * pl.h.kidx_step[a];
+                                const int kx = pl.w.kidx0[g] + tw * pl.w.kidx_step[g];
+                                for (int hf = 0; hf < 2; ++hf) {
+                                    const int ci = chunk * pl.ci_chunk + cp * 2 + hf;
+                                    for (int nb = 0; nb < pl.NB; ++nb, ++dst) {
+                                        const int co = cb * pl.NB + nb;
+                                        if (ci >= C || co >= K) continue;
+                                        const size_t src = d->transposed
+                                            ? (((size_t)ci * K + co) * KH + ky) * KW + kx
+                                            : (((size_t)co * C + ci) * KH + ky) * KW + kx;
+                                        *dst = w[src];
+                                    }
+                                }
+                            }
+    }
+    return UNETMI_OK;
+}
+
+int unetmi_conv2d_fwd(const UnetmiConvDesc* d, const float* in0, const float* in1,
+                      const float* wpacked, const float* bias, const float* scale,
+                      const float* shift, const float* act_param, const float* gate,
+                      const float* residual, float* out, void* stream) {
+    if (!d) return fail(UNETMI_E_BAD_ARG, "null descriptor");
+    ConvPlan pl;
+    std::string err;
+    if (!make_plan(*d, &pl, &err)) return fail(UNETMI_E_BAD_DESC, err);
+    if (d->N == 0) return UNETMI_OK;   // empty batch: nothing to read or write
+    if (!in0 || !wpacked || !bias || !scale || !shift || !out)
+        return fail(UNETMI_E_BAD_ARG, "null tensor pointer");
+    if (d->in_mode != UNETMI_IN_SINGLE && !in1) return fail(UNETMI_E_BAD_ARG, "in_mode needs in1");
+    if (d->act == UNETMI_ACT_LEAKY && !act_param) return fail(UNETMI_E_BAD_ARG, "leaky/prelu needs act_param");
+    if ((d->has_gate != 0) != (gate != nullptr)) return fail(UNETMI_E_BAD_ARG, "gate pointer vs has_gate");
+    if ((d->has_residual != 0) != (residual != nullptr))
+        return fail(UNETMI_E_BAD_ARG, "residual pointer vs has_residual");
+    if (pl.lds_bytes > 64 * 1024) return fail(UNETMI_E_UNSUPPORTED, "LDS tile exceeds 64 KB");
+    const hipError_t e = launch_conv_mfma(*d, pl, in0, in1, wpacked, bias, scale, shift, act_param,
+                                          gate, residual, out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(UNETMI_E_HIP, std::string("conv launch: ") + hipGetErrorString(e));
+    return UNETMI_OK;
+}
+
+}  // extern "C"

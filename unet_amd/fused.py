@@ -1,0 +1,162 @@
+"""Host logic of a fused convolution layer.
+
+``FusedConv`` owns nothing but caches: the packed weight image and the folded
+epilogue vectors of one (conv | transposed conv) [+ BatchNorm2d] [+ activation]
+group, rebuilt whenever a source parameter changes (tracked by tensor version
+counters and storage pointers) or the layer is first used on a device.  The
+parameters themselves stay in the ordinary ``nn.Conv2d`` / ``nn.BatchNorm2d``
+submodules, so ``state_dict`` keys and initialisation are the reference's.
+"""
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import conv2d_fwd, pack_conv_weights
+
+
+def _pair(v):
+    if isinstance(v, (tuple, list)):
+        if len(v) == 1:
+            return int(v[0]), int(v[0])
+        return int(v[0]), int(v[1])
+    return int(v), int(v)
+
+
+def activation_code(act):
+    """(code, parameter source) for an activation module, or None when the
+    module is not one the kernel epilogue implements."""
+    if act is None or isinstance(act, nn.Identity):
+        return _lib.ACT_NONE, None
+    if isinstance(act, nn.LeakyReLU):
+        return _lib.ACT_LEAKY, float(act.negative_slope)
+    if isinstance(act, nn.PReLU):
+        return _lib.ACT_LEAKY, act.weight
+    if isinstance(act, nn.ReLU):
+        return _lib.ACT_RELU, None
+    if isinstance(act, nn.SiLU):
+        return _lib.ACT_SILU, None
+    if isinstance(act, nn.Softplus) and act.beta == 1 and act.threshold == 20:
+        return _lib.ACT_SOFTPLUS, None
+    if isinstance(act, nn.Sigmoid):
+        return _lib.ACT_SIGMOID, None
+    if isinstance(act, nn.Tanh):
+        return _lib.ACT_TANH, None
+    if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none":
+        return _lib.ACT_GELU, None
+    return None
+
+
+def require_device_tensor(x, who):
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise RuntimeError(
+            "{}: the forward runs only on an MI355X device tensor (got {}); this package has no "
+            "CPU path".format(who, "a CPU tensor" if isinstance(x, torch.Tensor) else type(x)))
+    if x.dtype != torch.float32:
+        raise RuntimeError("{}: expected float32 input, got {}".format(who, x.dtype))
+
+
+class FusedConv:
+    """conv [+ BatchNorm2d(eval)] [+ activation] as ONE kernel launch."""
+
+    def __init__(self, conv, norm=None, act=None, act_first=False):
+        self.conv, self.norm, self.act, self.act_first = conv, norm, act, bool(act_first)
+        self._key = None
+        self._state = None
+
+    # -- what can be fused -------------------------------------------------------
+    def fusable(self):
+        c = self.conv
+        if c.groups != 1 or isinstance(c.padding, str):
+            return False
+        if isinstance(c, nn.Conv2d) and c.padding_mode != "zeros":
+            return False
+        if self.norm is not None and not isinstance(self.norm, nn.Identity):
+            n = self.norm
+            if not isinstance(n, nn.BatchNorm2d) or n.training or n.running_mean is None:
+                return False
+        return activation_code(self.act) is not None
+
+    def geometry(self):
+        c = self.conv
+        transposed = isinstance(c, nn.ConvTranspose2d)
+        kh, kw = _pair(c.kernel_size)
+        sh, sw = _pair(c.stride)
+        ph, pw = _pair(c.padding)
+        dh, dw = _pair(c.dilation)
+        oph, opw = _pair(c.output_padding) if transposed else (0, 0)
+        return [c.out_channels, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw], int(transposed)
+
+    # -- cache ---------------------------------------------------------------------
+    def _sources(self):
+        src = [self.conv.weight, self.conv.bias]
+        n = self.norm
+        if isinstance(n, nn.BatchNorm2d):
+            src += [n.weight, n.bias, n.running_mean, n.running_var]
+        if isinstance(self.act, nn.PReLU):
+            src.append(self.act.weight)
+        return src
+
+    def _cache_key(self, device):
+        return (str(device), self.act_first, type(self.act).__name__) + tuple(
+            (t._version, t.data_ptr()) if t is not None else None for t in self._sources())
+
+    def invalidate(self):
+        self._key = None
+
+    def _prepare(self, device):
+        key = self._cache_key(device)
+        if key == self._key:
+            return self._state
+        c = self.conv
+        geom, transposed = self.geometry()
+        K = c.out_channels
+        found = activation_code(self.act)
+        code, par = found if found is not None else (_lib.ACT_NONE, None)
+        with torch.no_grad():
+            wpacked = pack_conv_weights(c.weight, c.in_channels, 0, geom,
+                                        [transposed, _lib.IN_SINGLE, code, 0]).to(device)
+            f32 = dict(dtype=torch.float32, device=device)
+            bias = (c.bias.detach().to(**f32) if c.bias is not None else torch.zeros(K, **f32)).contiguous()
+            n = self.norm
+            if isinstance(n, nn.BatchNorm2d):
+                inv = torch.rsqrt(n.running_var.detach().to(**f32) + n.eps)
+                gamma = n.weight.detach().to(**f32) if n.weight is not None else torch.ones(K, **f32)
+                beta = n.bias.detach().to(**f32) if n.bias is not None else torch.zeros(K, **f32)
+                scale = (gamma * inv).contiguous()
+                shift = (beta - n.running_mean.detach().to(**f32) * scale).contiguous()
+            else:
+                scale, shift = torch.ones(K, **f32), torch.zeros(K, **f32)
+            if isinstance(par, torch.Tensor):
+                act_param = par.detach().to(**f32).reshape(-1).contiguous()
+                if act_param.numel() not in (1, K):
+                    raise ValueError("PReLU with {} parameters on {} channels".format(act_param.numel(), K))
+            elif par is not None:
+                act_param = torch.full((1,), par, **f32)
+            else:
+                act_param = None
+        self._state = dict(wpacked=wpacked, bias=bias, scale=scale, shift=shift, act_param=act_param,
+                           geom=geom, transposed=transposed, act=code)
+        self._key = key
+        return self._state
+
+    # -- launch ----------------------------------------------------------------------
+    def __call__(self, x, x2=None, in_mode=None, gate=None, residual=None, epilogue=True):
+        """x2 with in_mode IN_CONCAT (default when x2 is given) or IN_ADD.
+        epilogue=False runs the bare convolution + bias (used when the norm or
+        activation around it is not one the kernel fuses)."""
+        st = self._prepare(x.device)
+        if x2 is None:
+            mode = _lib.IN_SINGLE
+        else:
+            mode = _lib.IN_CONCAT if in_mode is None else in_mode
+        cin = x.shape[1] + (x2.shape[1] if (x2 is not None and mode == _lib.IN_CONCAT) else 0)
+        if cin != self.conv.in_channels:
+            raise RuntimeError("expected {} input channels, got {}".format(self.conv.in_channels, cin))
+        if epilogue:
+            return conv2d_fwd(x, x2, st["wpacked"], st["bias"], st["scale"], st["shift"],
+                              st["act_param"], gate, residual, st["geom"],
+                              [st["transposed"], mode, st["act"], int(self.act_first)])
+        ones = torch.ones_like(st["bias"])
+        return conv2d_fwd(x, x2, st["wpacked"], st["bias"], ones, torch.zeros_like(ones), None, gate,
+                          residual, st["geom"], [st["transposed"], mode, _lib.ACT_NONE, 0])

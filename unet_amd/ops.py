@@ -1,0 +1,141 @@
+"""torch.library registration of the libunetmi.so entry points.
+
+``torch.ops.unetmi.conv2d_fwd`` is the fused convolution layer
+(include/unetmi.h: unetmi_conv2d_fwd).  Its only implementation is the HIP
+kernel, registered for the CUDA dispatch key (ROCm tensors dispatch there);
+CPU tensors have no kernel and raise.  ``register_fake`` gives shape inference.
+"""
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+_LIBRARY = torch.library.Library("unetmi", "DEF")
+_LIBRARY.define(
+    "conv2d_fwd(Tensor in0, Tensor? in1, Tensor wpacked, Tensor bias, Tensor scale, Tensor shift, "
+    "Tensor? act_param, Tensor? gate, Tensor? residual, int[] geom, int[] flags) -> Tensor")
+
+# geom  = [K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw]
+# flags = [transposed, in_mode, act, act_first]
+
+
+def conv_out_size(size, k, s, p, d, op, transposed):
+    if transposed:
+        return (size - 1) * s - 2 * p + d * (k - 1) + op + 1
+    return (size + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def make_desc(N, C0, C1, H, W, geom, flags, act_pc=0, has_gate=0, has_residual=0):
+    K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
+    transposed, in_mode, act, act_first = flags
+    d = ConvDesc()
+    d.N, d.C0, d.C1, d.H, d.W, d.K = N, C0, C1, H, W, K
+    d.OH = conv_out_size(H, kh, sh, ph, dh, oph, transposed)
+    d.OW = conv_out_size(W, kw, sw, pw, dw, opw, transposed)
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw, d.oph, d.opw = kh, kw, sh, sw, ph, pw, dh, dw, oph, opw
+    d.transposed, d.in_mode, d.act, d.act_first = transposed, in_mode, act, act_first
+    d.act_param_per_channel, d.has_gate, d.has_residual = act_pc, has_gate, has_residual
+    return d
+
+
+def pack_conv_weights(weight, C0, C1, geom, flags):
+    """Host-side repack of a torch-layout weight into the kernel's image
+    (unetmi_conv2d_pack_weights).  Returns a CPU float32 tensor."""
+    d = make_desc(1, C0, C1, 64, 64, geom, flags)
+    # H/W do not enter the image; give the descriptor any consistent sizes
+    d.H = d.W = 64
+    d.OH = conv_out_size(64, d.kh, d.sh, d.ph, d.dh, d.oph, d.transposed)
+    d.OW = conv_out_size(64, d.kw, d.sw, d.pw, d.dw, d.opw, d.transposed)
+    nbytes = _lib.lib.unetmi_conv2d_packed_weight_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        raise _lib.UnetmiError("packed_weight_bytes: " + _lib.last_error())
+    w = weight.detach().to("cpu", torch.float32).contiguous()
+    packed = torch.empty(nbytes // 4, dtype=torch.float32)
+    check(_lib.lib.unetmi_conv2d_pack_weights(ctypes.byref(d), w.data_ptr(), packed.data_ptr()),
+          "unetmi_conv2d_pack_weights")
+    return packed
+
+
+# Optional per-launch observer (bench.py's roofline leg): called as
+# fn(op_name, desc, start_event, end_event) with torch.cuda events recorded on
+# the launch stream immediately around the kernel.
+_launch_observer = None
+
+
+def set_launch_observer(fn):
+    global _launch_observer
+    _launch_observer = fn
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need(t, name, shape=None):
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError("unetmi::conv2d_fwd: {} must be a contiguous fp32 device tensor".format(name))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("unetmi::conv2d_fwd: {} has shape {}, expected {}".format(
+            name, tuple(t.shape), tuple(shape)))
+
+
+def _conv2d_fwd_cuda(in0, in1, wpacked, bias, scale, shift, act_param, gate, residual, geom, flags):
+    _need(in0, "in0")
+    N, C0, H, W = in0.shape
+    C1 = 0
+    if in1 is not None:
+        _need(in1, "in1")
+        if in1.shape[0] != N or tuple(in1.shape[2:]) != (H, W):
+            raise ValueError("unetmi::conv2d_fwd: in1 {} does not match in0 {}".format(
+                tuple(in1.shape), tuple(in0.shape)))
+        C1 = in1.shape[1]
+    K = geom[0]
+    act_pc = 1 if (act_param is not None and act_param.numel() > 1) else 0
+    d = make_desc(N, C0, C1, H, W, geom, flags, act_pc, int(gate is not None), int(residual is not None))
+    for t, name in ((bias, "bias"), (scale, "scale"), (shift, "shift")):
+        _need(t, name, (K,))
+    _need(wpacked, "wpacked")
+    if act_param is not None:
+        _need(act_param, "act_param", (K,) if act_pc else (1,))
+    out = torch.empty((N, K, d.OH, d.OW), dtype=torch.float32, device=in0.device)
+    if gate is not None:
+        _need(gate, "gate", (N, K))
+    if residual is not None:
+        _need(residual, "residual", out.shape)
+    expect = _lib.lib.unetmi_conv2d_packed_weight_bytes(ctypes.byref(d))
+    if expect == 0:
+        raise _lib.UnetmiError("unetmi::conv2d_fwd: " + _lib.last_error())
+    if wpacked.numel() * 4 != expect:
+        raise ValueError("unetmi::conv2d_fwd: packed weight image has {} bytes, expected {}".format(
+            wpacked.numel() * 4, expect))
+    with torch.cuda.device(in0.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        obs = _launch_observer
+        if obs is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        check(_lib.lib.unetmi_conv2d_fwd(ctypes.byref(d), _ptr(in0), _ptr(in1), _ptr(wpacked),
+                                         _ptr(bias), _ptr(scale), _ptr(shift), _ptr(act_param),
+                                         _ptr(gate), _ptr(residual), _ptr(out), stream),
+              "unetmi_conv2d_fwd")
+        if obs is not None:
+            ev1.record()
+            obs("conv2d_fwd", d, ev0, ev1)
+    return out
+
+
+_LIBRARY.impl("conv2d_fwd", _conv2d_fwd_cuda, "CUDA")
+
+
+@torch.library.register_fake("unetmi::conv2d_fwd")
+def _conv2d_fwd_fake(in0, in1, wpacked, bias, scale, shift, act_param, gate, residual, geom, flags):
+    K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
+    N, _, H, W = in0.shape
+    return in0.new_empty((N, K, conv_out_size(H, kh, sh, ph, dh, oph, flags[0]),
+                          conv_out_size(W, kw, sw, pw, dw, opw, flags[0])))
+
+
+conv2d_fwd = torch.ops.unetmi.conv2d_fwd
