@@ -56,9 +56,13 @@ def conv_macs(d):
 
 def kernel_variant(d):
     """Which conv_mfma_kernel instantiation serves this layer."""
+    cin = d.C0 + (d.C1 if d.in_mode == 1 else 0)
+    if (d.kw == 1 and d.sw == 1 and d.sh == 1 and d.dh == 1 and d.kh in (1, 3, 7)
+            and (d.K <= 2 or (d.K <= 32 and cin * d.kh <= 112))):
+        return "direct_conv_kernel"
     ng = d.sw if d.transposed else 1
     wn = 1 if d.K <= 32 else 2
-    return "conv_mfma_kernel<{},{},{},{}>".format(ng, 4 // ng, 4 // wn, wn)
+    return "conv_mfma_kernel<{},{},{},{},{}>".format(ng, 4 // ng, 4 // wn, wn, "true" if d.in_mode == 2 else "false")
 
 
 def cpu_baseline(threads):
@@ -87,6 +91,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="per-layer times of the last step on stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,8 +124,11 @@ def main():
         torch.cuda.synchronize()
 
         records = []
-        ops.set_launch_observer(lambda name, d, e0, e1: records.append(
-            (kernel_variant(d), conv_macs(d), e0, e1)))
+        shapes = []
+        ops.set_launch_observer(lambda name, d, e0, e1: (records.append(
+            (kernel_variant(d), conv_macs(d), e0, e1)), shapes.append(
+            "{}{}+{}->{} k{}x{} s{}x{} out {}x{}".format("T" if d.transposed else "C", d.C0, d.C1, d.K,
+                                                      d.kh, d.kw, d.sh, d.sw, d.OH, d.OW))))
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -137,6 +145,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    if rank == 0 and args.layers:
+        per_step = len(records) // args.steps
+        for (variant, macs, e0, e1), shape in zip(records[-per_step:], shapes[-per_step:]):
+            ms = e0.elapsed_time(e1)
+            print("{:42s} {:34s} {:8.3f} ms {:7.1f} TFLOP/s".format(
+                shape, variant, ms, 2e-9 * macs / ms), file=sys.stderr)
     if rank == 0:
         per_variant = {}
         for variant, macs, e0, e1 in records:

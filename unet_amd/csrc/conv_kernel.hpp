@@ -1,0 +1,338 @@
+// Kernel template of the implicit-GEMM convolution (see conv_mfma.hip for the design
+// notes).  Included by the instantiation units conv_inst_*.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv_plan.hpp"
+
+namespace unetmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const float* in0; const float* in1; const float* wpacked;
+    const float* bias; const float* scale; const float* shift; const float* act_param;
+    const float* gate; const float* residual; float* out;
+    int N, C0, C1, Ctot, H, W, K, OH, OW;
+    int in_mode, act, act_first, act_pc;
+    int h_nphase, h_in_step, h_tap_step;
+    int h_ntap[kMaxPhase], h_base[kMaxPhase], h_nout[kMaxPhase];
+    int w_nphase, w_in_step, w_tap_step;
+    int w_ntap[kMaxPhase], w_base[kMaxPhase], w_nout[kMaxPhase];
+    int w_colmin;
+    int ci_chunk, nchunk, NB, nco_blk, TI;
+    int nrows, ncols, plane, in_tile_floats;
+    int wtaps[kMaxPhase];
+    unsigned long long w_phase_off[kMaxPhase];
+    int nit[kMaxPhase], njt;
+    unsigned blk_end[kMaxPhase];      // exclusive prefix end of each row phase's blocks
+    unsigned magic_ncols, magic_nrows;  // ceil(2^32 / d) for division of small numbers
+#ifdef UNETMI_ABLATE
+    int ablate;                        // developer probe only (tools/conv_probe.hip)
+#endif
+};
+
+#ifdef UNETMI_ABLATE
+extern int g_ablate;
+#define ABLATE(bit) (p.ablate & (bit))
+#else
+#define ABLATE(bit) false
+#endif
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case UNETMI_ACT_LEAKY:    return v >= 0.f ? v : v * slope;
+        case UNETMI_ACT_RELU:     return fmaxf(v, 0.f);
+        case UNETMI_ACT_SILU:     return v / (1.f + expf(-v));
+        case UNETMI_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
+        case UNETMI_ACT_SIGMOID:  return 1.f / (1.f + expf(-v));
+        case UNETMI_ACT_TANH:     return tanhf(v);
+        case UNETMI_ACT_GELU:     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        default:                  return v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// The MFMA loop.  Measured on gfx950: a v_mov into a register that an MFMA reads
+// (the usual "next = load; cur = next" software pipeline) costs ~20 % of the
+// matrix rate, and so does bunching the LDS reads after the last MFMA of a step.
+// So operands live in two fixed register sets that alternate per tap (no copies),
+// each tap's LDS reads are issued between the MFMAs of the previous tap, and the
+// tap loop is unrolled so that set indices and LDS offsets are compile-time.
+//
+// A "row" is NTW taps at consecutive columns of one (channel pair, tap row); its
+// reads are base-register + immediate.  NTW = 0 selects the generic form, where a
+// row is a single tap and the walk also steps the column at run time.
+// ---------------------------------------------------------------------------------
+template <int TPG, int NTW, int ROWS, int NB>
+__device__ __forceinline__ void mfma_rows(f32x16 (&acc)[TPG], float (&a)[2], float (&b)[2][TPG],
+                                          const float* wp, const float* const (&rows)[ROWS + 1][TPG]) {
+    constexpr int NT = ROWS * NTW;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        const int nr = (i + 1) / NTW, nc = (i + 1) % NTW;   // row / column of the NEXT tap
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur], b[cur][t], acc[t], 0, 0, 0);
+            if (t == 0) {
+                a[nxt] = wp[(i + 1) * 2 * NB];
+                b[nxt][0] = rows[nr][0][nc];
+                if (TPG == 2) b[nxt][1] = rows[nr][1][nc];
+            }
+            if (TPG == 4 && t == 1) { b[nxt][1] = rows[nr][1][nc]; b[nxt][2] = rows[nr][2][nc]; }
+            if (TPG == 4 && t == 2) b[nxt][3] = rows[nr][3][nc];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int TPG, int NTW, int NB>
+__device__ __forceinline__ void group_mfma(f32x16 (&acc)[TPG], const float* s_in, const float* wp,
+                                           const int (&ib)[TPG], int cpc, int nth, int ntw_rt,
+                                           const ConvArgs& p) {
+    constexpr bool GENERIC = NTW == 0;
+    constexpr int NTWE = GENERIC ? 1 : NTW;
+    const int R = ABLATE(2) ? 0 : (GENERIC ? cpc * nth * ntw_rt : cpc * nth);
+    if (R == 0) return;
+    const int row_stride = p.h_tap_step * p.ncols;
+    const int col_step = p.w_tap_step;
+    const int row_wrap = row_stride - ntw_rt * col_step;       // generic: end of a tap row
+    const int pair_wrap = 2 * p.plane - nth * row_stride;      // end of a channel pair
+    int tw = 0, th = 0;
+    auto advance = [&]() -> int {                              // offset from this row to the next
+        int d;
+        if (GENERIC) {
+            ++tw; d = col_step;
+            if (tw == ntw_rt) { tw = 0; d += row_wrap; ++th; if (th == nth) { th = 0; d += pair_wrap; } }
+        } else {
+            ++th; d = row_stride;
+            if (th == nth) { th = 0; d += pair_wrap; }
+        }
+        return d;
+    };
+    const float* rp[3][TPG];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) rp[0][t] = s_in + ib[t];
+    float a[2], b[2][TPG];
+    a[0] = wp[0];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) b[0][t] = rp[0][t][0];
+    int r = 0;
+    for (; r + 2 <= R; r += 2) {
+        const int d1 = advance();
+        const int d2 = (r + 2 < R) ? advance() : 0;            // past the end: re-read the last row
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) { rp[1][t] = rp[0][t] + d1; rp[2][t] = rp[1][t] + d2; }
+        mfma_rows<TPG, NTWE, 2, NB>(acc, a, b, wp, rp);
+        wp += 2 * NTWE * 2 * NB;
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) rp[0][t] = rp[2][t];
+    }
+    if (r < R) {
+        const float* last[2][TPG];
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) { last[0][t] = rp[0][t]; last[1][t] = rp[0][t]; }
+        mfma_rows<TPG, NTWE, 1, NB>(acc, a, b, wp, last);
+    }
+}
+
+
+template <int NG, int TPG, int WM, int WN, bool TWO, int NTW0, int NTW1>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;
+    float* s_w = smem + p.in_tile_floats;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, j = lane & 31;
+
+    // ---- which tile is this workgroup's -----------------------------------
+    unsigned bid = blockIdx.x;
+    int a = 0;
+    unsigned start = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxPhase - 1; ++q)
+        if (q + 1 < p.h_nphase && bid >= p.blk_end[q]) { a = q + 1; start = p.blk_end[q]; }
+    bid -= start;
+    const int cb = bid % p.nco_blk; bid /= p.nco_blk;
+    const int jt = bid % p.njt;     bid /= p.njt;
+    const int it = bid % p.nit[a];  bid /= p.nit[a];
+    const int n = bid;
+    const int i0 = it * p.TI, j0 = jt * kTileJ;
+    const int nth = p.h_ntap[a];
+    const int row0 = i0 * p.h_in_step + p.h_base[a];
+    const int col0 = j0 * p.w_in_step + p.w_colmin;
+    const int cpc = p.ci_chunk >> 1;
+    const int chunk_w_floats = cpc * p.wtaps[a] * 2 * p.NB;
+    const int HW = p.H * p.W;
+
+    f32x16 acc[NG][TPG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int t = 0; t < TPG; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][t][r] = 0.f;
+
+    // per-lane LDS offsets of the B operand (input patch) for each accumulator tile
+    int ib[NG][TPG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int t = 0; t < TPG; ++t)
+            ib[g][t] = half * p.plane + ((wm * TPG + t) * p.h_in_step) * p.ncols +
+                       j * p.w_in_step + (p.w_base[g] - p.w_colmin);
+    const int wlane = half * p.NB + wn * 32 + j;
+
+    // ---- per-thread prefetch slots: element e = s*256 + tid of the chunk image ----
+    // Every load below is an unconditional buffer load: lanes that fall outside
+    // the image, past the last channel, or in an unused slot carry an offset
+    // beyond the descriptor's range and get 0 back without touching memory.  No
+    // branch surrounds a load, so all of a chunk's loads are in flight together.
+    const int in_elems = p.ci_chunk * p.plane;
+    const int nin_slots = (in_elems + 255) >> 8;
+    const int n4 = chunk_w_floats >> 2;
+    const int nw_slots = (n4 + 255) >> 8;
+    constexpr int kOutside = (int)0x80000000;
+    int voff[kMaxInSlots];             // byte offset inside the chunk's channel block
+#pragma unroll
+    for (int s = 0; s < kMaxInSlots; ++s) {
+        const int e = s * 256 + tid;
+        const int rr = __umulhi((unsigned)e, p.magic_ncols);
+        const int c = e - rr * p.ncols;
+        const int cl = (p.nrows == 1) ? rr : (int)__umulhi((unsigned)rr, p.magic_nrows);
+        const int r = rr - cl * p.nrows;
+        const int grow = row0 + r, gcol = col0 + c;
+        const bool ok = e < in_elems && (unsigned)grow < (unsigned)p.H && (unsigned)gcol < (unsigned)p.W;
+        voff[s] = ok ? (cl * HW + grow * p.W + gcol) * 4 : kOutside;
+    }
+    float rin[kMaxInSlots];
+    float rin2[TWO ? kMaxInSlots : 1];
+    f32x4 rw[kMaxW4Slots];
+    const float* wsrc_base = p.wpacked + p.w_phase_off[a] + (size_t)cb * p.nchunk * chunk_w_floats;
+
+    auto prefetch = [&](int chunk) {
+        const bool live = chunk < p.nchunk && !(ABLATE(8) && chunk > 0);   // else: every load out of range
+        const int ci_base = chunk * p.ci_chunk;
+        // source 0: in0 channels [ci_base, ...) ; source 1: in1 (concat tail, or the addend)
+        int ch0, ch1 = 0;
+        long long first0, first1 = 0;
+        int shift1 = 0;                               // byte shift of source-1 offsets
+        if (p.in_mode == UNETMI_IN_CONCAT) {
+            if (TWO) {
+                ch0 = min(max(p.C0 - ci_base, 0), p.ci_chunk);
+                first0 = (long long)n * p.C0 + ci_base;
+                ch1 = p.C1;                           // addressed from in1's channel 0 of image n
+                first1 = (long long)n * p.C1;
+                shift1 = (ci_base - p.C0) * HW * 4;   // negative offsets wrap to out-of-range
+            } else if (ci_base < p.C0) {              // chunk wholly inside in0 (launcher guarantees)
+                ch0 = min(p.ci_chunk, p.C0 - ci_base);
+                first0 = (long long)n * p.C0 + ci_base;
+            } else {                                  // chunk wholly inside in1
+                ch0 = min(p.ci_chunk, p.Ctot - ci_base);
+                first0 = (long long)n * p.C1 + (ci_base - p.C0);
+            }
+        } else {
+            ch0 = min(p.ci_chunk, p.Ctot - ci_base);
+            first0 = (long long)n * p.C0 + ci_base;
+            if (TWO) { ch1 = ch0; first1 = first0; }
+        }
+        const float* base0 = (p.in_mode == UNETMI_IN_CONCAT && !TWO && ci_base >= p.C0) ? p.in1 : p.in0;
+        const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(base0 + first0 * HW), 0, live ? ch0 * HW * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int s = 0; s < kMaxInSlots; ++s)
+            rin[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, voff[s], 0, 0));
+        if (TWO) {
+            const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.in1 + first1 * HW), 0, live ? ch1 * HW * 4 : 0, 0x00020000);
+#pragma unroll
+            for (int s = 0; s < kMaxInSlots; ++s)
+                rin2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs1, voff[s] + shift1, 0, 0));
+        }
+        const auto rsw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(wsrc_base + (size_t)(live ? chunk : 0) * chunk_w_floats), 0,
+            live ? chunk_w_floats * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int s = 0; s < kMaxW4Slots; ++s)
+            rw[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rsw, (s * 256 + tid) * 16, 0, 0));
+    };
+
+    prefetch(0);
+    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+        __syncthreads();   // every wave is done reading the previous chunk from LDS
+        if (!(ABLATE(1) && chunk > 0)) {
+#pragma unroll
+        for (int s = 0; s < kMaxInSlots; ++s)
+            if (s < nin_slots)     // LDS image is padded to whole slots: no per-lane guard
+                s_in[s * 256 + tid] = TWO ? rin[s] + rin2[s] : rin[s];
+#pragma unroll
+        for (int s = 0; s < kMaxW4Slots; ++s)
+            if (s < nw_slots) reinterpret_cast<f32x4*>(s_w)[s * 256 + tid] = rw[s];
+        }
+        __syncthreads();
+        prefetch(chunk + 1);       // in flight while this chunk computes
+
+        // ---- MFMA over (column phase; channel pair x tap row x tap col) -------------
+        {
+            const float* wp = s_w + wlane;
+            group_mfma<TPG, NTW0, 32 * WN>(acc[0], s_in, wp, ib[0], cpc, nth, p.w_ntap[0], p);
+            if (NG == 2) {
+                wp += cpc * nth * p.w_ntap[0] * 2 * p.NB;
+                group_mfma<TPG, NTW1, 32 * WN>(acc[NG - 1], s_in, wp, ib[NG - 1], cpc, nth, p.w_ntap[1], p);
+            }
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------
+    const int co_base = cb * p.NB + wn * 32 + 4 * half;
+    const size_t OHW = (size_t)p.OH * p.OW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co_base + (r & 3) + 8 * (r >> 2);
+        if (co >= p.K) continue;
+        const float b = p.bias[co], sc = p.scale[co], sf = p.shift[co];
+        const float slope = p.act_param ? p.act_param[p.act_pc ? co : 0] : 0.f;
+        const float gt = p.gate ? p.gate[(size_t)n * p.K + co] : 1.f;
+        const size_t chan = ((size_t)n * p.K + co) * OHW;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int jj = j0 + j;
+            const int ow = jj * p.w_nphase + g;
+            const bool col_ok = jj < p.w_nout[g];
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) {
+                const int i = i0 + wm * TPG + t;
+                if (i >= p.h_nout[a] || !col_ok) continue;
+                const int oh = i * p.h_nphase + a;
+                float v = acc[g][t][r] + b;
+                if (p.act_first) v = apply_act(v, p.act, slope) * sc + sf;
+                else             v = apply_act(v * sc + sf, p.act, slope);
+                v *= gt;
+                const size_t o = chan + (size_t)oh * p.OW + ow;
+                if (p.residual) v += p.residual[o];
+                if (!ABLATE(4) || v == 123.456f) p.out[o] = v;
+            }
+        }
+    }
+}
+
+template <int NG, int TPG, int WM, int WN, bool TWO, int NTW0, int NTW1>
+inline void launch_conv_variant(unsigned grid, size_t lds, hipStream_t stream, const ConvArgs& p) {
+    hipLaunchKernelGGL((conv_mfma_kernel<NG, TPG, WM, WN, TWO, NTW0, NTW1>), dim3(grid), dim3(256), lds,
+                       stream, p);
+}
+
+// Instantiation units.  Each returns false when it holds no kernel for the request.
+bool launch_conv_generic(int ng, int wn, bool two, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
+bool launch_conv_ng1(int wn, int ntw0, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
+bool launch_conv_ng2(int wn, int ntw0, int ntw1, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
+
+}  // namespace unetmi

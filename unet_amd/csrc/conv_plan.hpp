@@ -16,7 +16,10 @@ namespace unetmi {
 constexpr int kMaxPhase = 4;      // output phases per axis = stride of a transposed conv
 constexpr int kWaves = 4;         // waves per workgroup
 constexpr int kTileJ = 32;        // output columns of one MFMA tile (the 32 of 32x32x2)
-constexpr int kLdsBudget = 64 * 1024;
+constexpr int kLdsBudget = 64 * 1024;   // staged images; the kernel may add < 1 KB of slack
+constexpr int kMaxInSlots = 24;   // input-patch floats a thread prefetches per chunk (x256 threads)
+constexpr int kMaxW4Slots = 10;   // weight float4s a thread prefetches per chunk
+constexpr int kMaxTaps = 64;      // taps of one (row phase, column phase) pair
 
 // One spatial axis.  Output index o = nphase * q + phase (q = "phase index").
 // Tap t of that phase reads input index  q * in_step + base[phase] + t * tap_step
@@ -86,7 +89,26 @@ struct ConvPlan {
     size_t lds_bytes = 0;
     int nit[kMaxPhase] = {0, 0, 0, 0};        // row tiles per row phase
     int njt = 1;                               // column tiles
+    // direct (vector-ALU) family for the thin layers; see direct_conv.hip
+    bool direct = false;
+    int direct_rpt = 8, direct_kt = 1, direct_kpad = 1, direct_pad = 0;
 };
+
+// Thin layers go to the direct kernel: kernel width 1, unit stride and dilation,
+// height 1/3/7, and either <= 2 output channels or (<= 32 outputs from <= 16 inputs).
+inline bool plan_direct(const UnetmiConvDesc& d, ConvPlan* pl) {
+    if (d.kw != 1 || d.sw != 1 || d.sh != 1 || d.dh != 1 || d.dw != 1 || d.pw != 0 || d.opw || d.oph) return false;
+    if (d.kh != 1 && d.kh != 3 && d.kh != 7) return false;
+    const int ctot = (d.in_mode == UNETMI_IN_CONCAT) ? d.C0 + d.C1 : d.C0;
+    if (d.K <= 2) { pl->direct_rpt = 8; pl->direct_kt = d.K; pl->direct_kpad = d.K; }
+    else if (d.K <= 32 && ctot * d.kh <= 16 * 7) { pl->direct_rpt = 2; pl->direct_kt = 16; pl->direct_kpad = (d.K + 15) & ~15; }
+    else return false;
+    // conv form: ih = oh - pad + kh'; a transposed layer is the flipped kernel with pad' = kh-1-p
+    pl->direct_pad = d.transposed ? (d.kh - 1 - d.ph) : d.ph;
+    if (pl->direct_pad < 0) return false;
+    pl->direct = true;
+    return true;
+}
 
 inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     if (d.N < 0 || d.C0 < 1 || d.C1 < 0 || d.K < 1) { *err = "bad channel/batch counts"; return false; }
@@ -101,6 +123,11 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     if (pl->w.nphase != 1 && pl->w.nphase != 2) { *err = "column stride of a transposed conv must be 1 or 2"; return false; }
 
     pl->Ctot = (d.in_mode == UNETMI_IN_CONCAT) ? d.C0 + d.C1 : d.C0;
+    if (plan_direct(d, pl)) {
+        pl->packed_floats = std::max<size_t>((size_t)pl->Ctot * d.kh * pl->direct_kpad, 4);
+        pl->lds_bytes = 0;
+        return true;
+    }
     pl->NB = (d.K <= 32) ? 32 : 64;
     pl->nco_blk = (d.K + pl->NB - 1) / pl->NB;
     pl->WN = pl->NB / 32; pl->WM = kWaves / pl->WN;
@@ -120,8 +147,12 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     if (cmin > cmax) { cmin = 0; cmax = 0; }
     pl->w_colmin = cmin;
     pl->ncols = (kTileJ - 1) * pl->w.in_step + (cmax - cmin) + 1;
-    pl->pitch = pl->ncols | 1;                      // odd pitch: rows start on different banks
+    pl->pitch = pl->ncols;          // flat [ci][row][col] image: LDS offset == element index
     pl->plane = pl->nrows * pl->pitch;
+    if (max_nth * std::max(pl->w.ntap[0], pl->w.ntap[1]) > kMaxTaps) { *err = "kernel window too large"; return false; }
+    if ((long long)d.H * d.W * 4 * std::max(std::max(d.C0, d.C1), 34) >= (1ll << 30)) {
+        *err = "image too large for 32-bit buffer offsets"; return false;
+    }
 
     int max_wtaps = 0;
     for (int a = 0; a < pl->h.nphase; ++a) {
@@ -133,6 +164,9 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     const size_t per_pair = (size_t)2 * pl->plane * 4 + (size_t)max_wtaps * 2 * pl->NB * 4;
     int max_pairs = (int)std::min<size_t>((size_t)kLdsBudget / std::max<size_t>(per_pair, 1), 16);
     max_pairs = std::min(max_pairs, cpad / 2);
+    // what one workgroup can hold in registers while the previous chunk computes
+    max_pairs = std::min(max_pairs, kMaxInSlots * 256 / (2 * pl->plane));
+    if (max_wtaps > 0) max_pairs = std::min(max_pairs, kMaxW4Slots * 1024 / (max_wtaps * 2 * pl->NB));
     if (max_pairs < 1) { *err = "one channel pair does not fit in LDS for this geometry"; return false; }
     // among chunk sizes in (max/2, max], take the one that pads the channel
     // count the least (padding is MFMA work on zeros); ties go to the larger
@@ -151,8 +185,10 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
         off += (size_t)pl->nco_blk * pl->nchunk * pairs * pl->wtaps[a] * 2 * pl->NB;
     }
     pl->packed_floats = std::max<size_t>(off, 4);
-    pl->in_tile_floats = (pl->ci_chunk * pl->plane + 3) & ~3;
-    pl->w_tile_floats = pairs * max_wtaps * 2 * pl->NB;
+    // both LDS images are padded to whole 256-thread slots so staging needs no per-lane guard
+    pl->in_tile_floats = (pl->ci_chunk * pl->plane + 255) & ~255;
+    // + one tap of slack: the MFMA loop reads one weight step past the last tap
+    pl->w_tile_floats = ((pairs * max_wtaps * 2 * pl->NB / 4 + 255) & ~255) * 4 + 2 * pl->NB;
     pl->lds_bytes = (size_t)(pl->in_tile_floats + pl->w_tile_floats) * 4;
 
     int max_nj = 0;

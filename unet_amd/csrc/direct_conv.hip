@@ -1,0 +1,146 @@
+// Direct (vector-ALU) convolution for the thin ends of the networks, where the
+// work is bandwidth- not matrix-bound: very few output channels (the last
+// decoder 96 -> 1, the 1x1 heads, ResUNet's 64 -> 2 output layer) or very few
+// input channels (the first encoder 2 -> 32).  Kernel height 1, 3 or 7 along
+// frequency, width 1, stride 1 -- the only shapes those layers take.
+//
+// A thread owns one time column and RPT consecutive frequency rows for KT output
+// channels: per input channel it loads RPT+KH-1 values once (rows shared by the
+// KH taps stay in registers) and its weights come through the scalar cache
+// (they are wave-uniform).  Lanes run along time, so every load and store of a
+// wave is one contiguous 256-byte run.  Same fused epilogue and the same
+// two-source (concat / add) input read as the MFMA kernel.
+#include <hip/hip_runtime.h>
+
+#include "conv_plan.hpp"
+
+namespace unetmi {
+
+struct DirectArgs {
+    const float* in0; const float* in1; const float* w;
+    const float* bias; const float* scale; const float* shift; const float* act_param;
+    const float* gate; const float* residual; float* out;
+    int N, C0, C1, Ctot, H, W, K, OH;
+    int in_mode, act, act_first, act_pc;
+    int pad;        // rows: ih = oh - pad + kh  (transposed layers are packed flipped)
+    int kpad;       // padded K of the weight image [ci][kh][kpad]
+    int nkt;        // K tiles
+};
+
+__device__ __forceinline__ float direct_act(float v, int act, float slope) {
+    switch (act) {
+        case UNETMI_ACT_LEAKY:    return v >= 0.f ? v : v * slope;
+        case UNETMI_ACT_RELU:     return fmaxf(v, 0.f);
+        case UNETMI_ACT_SILU:     return v / (1.f + expf(-v));
+        case UNETMI_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
+        case UNETMI_ACT_SIGMOID:  return 1.f / (1.f + expf(-v));
+        case UNETMI_ACT_TANH:     return tanhf(v);
+        case UNETMI_ACT_GELU:     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        default:                  return v;
+    }
+}
+
+template <int RPT, int KT, int KH>
+__global__ __launch_bounds__(256) void direct_conv_kernel(const DirectArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ow = blockIdx.x * 64 + lane;
+    const int oh0 = (blockIdx.y * 4 + wave) * RPT;
+    const int n = blockIdx.z / p.nkt;
+    const int k0 = (blockIdx.z % p.nkt) * KT;
+    if (oh0 >= p.OH) return;                       // wave-uniform
+    const bool col_ok = ow < p.W;
+    const int HW = p.H * p.W;
+    constexpr int NX = RPT + KH - 1;
+
+    float acc[KT][RPT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) acc[kk][r] = 0.f;
+
+    // row validity is the same for every channel
+    int roff[NX];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+        const int ih = oh0 - p.pad + q;
+        roff[q] = (col_ok && (unsigned)ih < (unsigned)p.H) ? ih * p.W + ow : -1;
+    }
+
+    for (int ci = 0; ci < p.Ctot; ++ci) {
+        const float* src;
+        const float* src2 = nullptr;
+        if (p.in_mode == UNETMI_IN_CONCAT && ci >= p.C0) src = p.in1 + ((size_t)n * p.C1 + (ci - p.C0)) * HW;
+        else src = p.in0 + ((size_t)n * p.C0 + ci) * HW;
+        if (p.in_mode == UNETMI_IN_ADD) src2 = p.in1 + ((size_t)n * p.C0 + ci) * HW;
+        float x[NX];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int o = roff[q] < 0 ? 0 : roff[q];
+            float v = src[o];
+            if (src2) v += src2[o];
+            x[q] = roff[q] < 0 ? 0.f : v;
+        }
+        const float* wrow = p.w + (size_t)ci * KH * p.kpad + k0;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) {
+                const float wv = wrow[kh * p.kpad + kk];
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) acc[kk][r] = fmaf(x[r + kh], wv, acc[kk][r]);
+            }
+    }
+
+    if (!col_ok) return;
+    const size_t OHW = (size_t)p.OH * p.W;
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+        const int co = k0 + kk;
+        if (co >= p.K) continue;
+        const float b = p.bias[co], sc = p.scale[co], sf = p.shift[co];
+        const float slope = p.act_param ? p.act_param[p.act_pc ? co : 0] : 0.f;
+        const float gt = p.gate ? p.gate[(size_t)n * p.K + co] : 1.f;
+        const size_t chan = ((size_t)n * p.K + co) * OHW;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int oh = oh0 + r;
+            if (oh >= p.OH) continue;
+            float v = acc[kk][r] + b;
+            if (p.act_first) v = direct_act(v, p.act, slope) * sc + sf;
+            else             v = direct_act(v * sc + sf, p.act, slope);
+            v *= gt;
+            const size_t o = chan + (size_t)oh * p.W + ow;
+            if (p.residual) v += p.residual[o];
+            p.out[o] = v;
+        }
+    }
+}
+
+hipError_t launch_direct_conv(const UnetmiConvDesc& d, const ConvPlan& pl,
+                              const float* in0, const float* in1, const float* wpacked,
+                              const float* bias, const float* scale, const float* shift,
+                              const float* act_param, const float* gate, const float* residual,
+                              float* out, hipStream_t stream) {
+    DirectArgs p;
+    p.in0 = in0; p.in1 = in1; p.w = wpacked; p.bias = bias; p.scale = scale; p.shift = shift;
+    p.act_param = act_param; p.gate = gate; p.residual = residual; p.out = out;
+    p.N = d.N; p.C0 = d.C0; p.C1 = d.C1; p.Ctot = pl.Ctot; p.H = d.H; p.W = d.W; p.K = d.K; p.OH = d.OH;
+    p.in_mode = d.in_mode; p.act = d.act; p.act_first = d.act_first; p.act_pc = d.act_param_per_channel;
+    p.pad = pl.direct_pad; p.kpad = pl.direct_kpad; p.nkt = pl.direct_kpad / pl.direct_kt;
+    const int rpt = pl.direct_rpt, kt = pl.direct_kt, kh = d.kh;
+    const dim3 grid((d.W + 63) / 64, (d.OH + 4 * rpt - 1) / (4 * rpt), (unsigned)d.N * p.nkt);
+    if (grid.z > 65535u * 16u) return hipErrorInvalidConfiguration;
+#define UNETMI_DIRECT(RPT_, KT_, KH_)                                                        \
+    if (rpt == RPT_ && kt == KT_ && kh == KH_) {                                             \
+        hipLaunchKernelGGL((direct_conv_kernel<RPT_, KT_, KH_>), grid, dim3(256), 0, stream, p); \
+        return hipGetLastError();                                                            \
+    }
+    UNETMI_DIRECT(8, 1, 1) UNETMI_DIRECT(8, 1, 3) UNETMI_DIRECT(8, 1, 7)
+    UNETMI_DIRECT(8, 2, 1) UNETMI_DIRECT(8, 2, 3) UNETMI_DIRECT(8, 2, 7)
+    UNETMI_DIRECT(2, 16, 1) UNETMI_DIRECT(2, 16, 3) UNETMI_DIRECT(2, 16, 7)
+#undef UNETMI_DIRECT
+    return hipErrorInvalidConfiguration;
+}
+
+}  // namespace unetmi

@@ -14,6 +14,12 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
                             const float* act_param, const float* gate, const float* residual,
                             float* out, hipStream_t stream);
 
+hipError_t launch_direct_conv(const UnetmiConvDesc& d, const ConvPlan& pl,
+                              const float* in0, const float* in1, const float* wpacked,
+                              const float* bias, const float* scale, const float* shift,
+                              const float* act_param, const float* gate, const float* residual,
+                              float* out, hipStream_t stream);
+
 static thread_local std::string g_last_error;
 
 static int fail(int code, const std::string& msg) {
@@ -50,12 +56,22 @@ int unetmi_conv2d_pack_weights(const UnetmiConvDesc* d, const float* w, float* p
     std::memset(packed, 0, pl.packed_floats * sizeof(float));
     const int cpc = pl.ci_chunk / 2;
     const int C = pl.Ctot, K = d->K, KH = d->kh, KW = d->kw;
+    if (pl.direct) {            // image [ci][kh'][kpad]; transposed layers flipped along kh
+        for (int ci = 0; ci < C; ++ci)
+            for (int kh = 0; kh < KH; ++kh)
+                for (int co = 0; co < K; ++co) {
+                    const size_t src = d->transposed ? (((size_t)ci * K + co) * KH + (KH - 1 - kh))
+                                                     : (((size_t)co * C + ci) * KH + kh);
+                    packed[((size_t)ci * KH + kh) * pl.direct_kpad + co] = w[src];
+                }
+        return UNETMI_OK;
+    }
     for (int a = 0; a < pl.h.nphase; ++a) {
         float* dst = packed + pl.w_phase_off[a];
         for (int cb = 0; cb < pl.nco_blk; ++cb)
             for (int chunk = 0; chunk < pl.nchunk; ++chunk)
-                for (int cp = 0; cp < cpc; ++cp)
-                    for (int g = 0; g < pl.w.nphase; ++g)
+                for (int g = 0; g < pl.w.nphase; ++g)       // image order == kernel read order
+                    for (int cp = 0; cp < cpc; ++cp)
                         for (int th = 0; th < pl.h.ntap[a]; ++th)
                             for (int tw = 0; tw < pl.w.ntap[g]; ++tw) {
                                 const int ky = pl.h.kidx0[a] + th * pl.h.kidx_step[a];
@@ -92,8 +108,8 @@ int unetmi_conv2d_fwd(const UnetmiConvDesc* d, const float* in0, const float* in
     if ((d->has_gate != 0) != (gate != nullptr)) return fail(UNETMI_E_BAD_ARG, "gate pointer vs has_gate");
     if ((d->has_residual != 0) != (residual != nullptr))
         return fail(UNETMI_E_BAD_ARG, "residual pointer vs has_residual");
-    if (pl.lds_bytes > 64 * 1024) return fail(UNETMI_E_UNSUPPORTED, "LDS tile exceeds 64 KB");
-    const hipError_t e = launch_conv_mfma(*d, pl, in0, in1, wpacked, bias, scale, shift, act_param,
+    if (pl.lds_bytes > 65 * 1024) return fail(UNETMI_E_UNSUPPORTED, "LDS tile exceeds 65 KB");
+    const hipError_t e = (pl.direct ? launch_direct_conv : launch_conv_mfma)(*d, pl, in0, in1, wpacked, bias, scale, shift, act_param,
                                           gate, residual, out, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(UNETMI_E_HIP, std::string("conv launch: ") + hipGetErrorString(e));
     return UNETMI_OK;
