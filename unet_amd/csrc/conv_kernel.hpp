@@ -22,22 +22,29 @@ struct ConvArgs {
     int w_ntap[kMaxPhase], w_base[kMaxPhase], w_nout[kMaxPhase];
     int w_colmin;
     int ci_chunk, nchunk, NB, nco_blk, TI;
-    int nrows, ncols, plane, in_tile_floats;
+    int nrows, ncols, plane, in_tile_floats, w_tile_floats;
     int wtaps[kMaxPhase];
     unsigned long long w_phase_off[kMaxPhase];
     int nit[kMaxPhase], njt;
     unsigned blk_end[kMaxPhase];      // exclusive prefix end of each row phase's blocks
     unsigned magic_ncols, magic_nrows;  // ceil(2^32 / d) for division of small numbers
+    int xcd_remap;                      // 1: one XCD walks a contiguous run of tiles
 #ifdef UNETMI_ABLATE
     int ablate;                        // developer probe only (tools/conv_probe.hip)
+    unsigned long long* stamps;
 #endif
 };
 
 #ifdef UNETMI_ABLATE
 extern int g_ablate;
+extern unsigned long long* g_stamps;   // [8] accumulated cycles per phase + block count (probe only)
+#define STAMP(i) do { if (p.stamps) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if (threadIdx.x == 0) atomicAdd(&p.stamps[i], t_ - t_last); t_last = t_; } } while (0)
 #define ABLATE(bit) (p.ablate & (bit))
 #else
 #define ABLATE(bit) false
+#define STAMP(i) do {} while (0)
 #endif
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -144,15 +151,28 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
     float* s_w = smem + p.in_tile_floats;
+    float* s_par = s_w + p.w_tile_floats;      // [5][NB]: bias, scale, shift, slope, gate
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+#ifdef UNETMI_ABLATE
+    unsigned long long t_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last) :: "memory");
+#endif
     const int half = lane >> 5, j = lane & 31;
 
     // ---- which tile is this workgroup's -----------------------------------
+    // Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  Re-number
+    // them so that one XCD walks a CONTIGUOUS run of tiles: neighbouring tiles share
+    // input halo rows/columns and the cache lines their output rows straddle, which
+    // then meet in one L2 instead of being written back as partial lines.
     unsigned bid = blockIdx.x;
+    if (p.xcd_remap) {
+        const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
     int a = 0;
     unsigned start = 0;
 #pragma unroll
@@ -265,9 +285,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                 rsw, (s * 256 + tid) * 16, 0, 0));
     };
 
+    // Epilogue parameters of this workgroup's output channels: fetched now, parked in
+    // LDS with the first chunk, read back in one batch by the epilogue (a global load
+    // per output register there would expose one memory round trip per register).
+    float par[5] = {0.f, 1.f, 0.f, 0.f, 1.f};
+    if (tid < p.NB) {
+        const int co = cb * p.NB + tid;
+        if (co < p.K) {
+            par[0] = p.bias[co]; par[1] = p.scale[co]; par[2] = p.shift[co];
+            if (p.act_param) par[3] = p.act_param[p.act_pc ? co : 0];
+            if (p.gate) par[4] = p.gate[(size_t)n * p.K + co];
+        }
+    }
+    STAMP(0);                      // prologue: tile decode, offsets
     prefetch(0);
+    STAMP(1);                      // issue of the first prefetch
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         __syncthreads();   // every wave is done reading the previous chunk from LDS
+        STAMP(2);                  // barrier after compute
         if (!(ABLATE(1) && chunk > 0)) {
 #pragma unroll
         for (int s = 0; s < kMaxInSlots; ++s)
@@ -277,8 +312,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         for (int s = 0; s < kMaxW4Slots; ++s)
             if (s < nw_slots) reinterpret_cast<f32x4*>(s_w)[s * 256 + tid] = rw[s];
         }
+        if (chunk == 0 && tid < p.NB) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) s_par[q * p.NB + tid] = par[q];
+        }
+        STAMP(3);                  // wait for the prefetch + LDS writes
         __syncthreads();
+        STAMP(4);                  // barrier after LDS writes
         prefetch(chunk + 1);       // in flight while this chunk computes
+        STAMP(5);                  // issue of the next prefetch
 
         // ---- MFMA over (column phase; channel pair x tap row x tap col) -------------
         {
@@ -291,20 +333,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         }
     }
 
+    STAMP(6);                      // MFMA loops (all chunks)
     // ---- epilogue ---------------------------------------------------------------
-    const int co_base = cb * p.NB + wn * 32 + 4 * half;
+    const int col_base = wn * 32 + 4 * half;          // this lane's first channel inside the block
     const size_t OHW = (size_t)p.OH * p.OW;
+    float e_b[16], e_sc[16], e_sf[16], e_sl[16], e_g[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int co = co_base + (r & 3) + 8 * (r >> 2);
+        const int cl = col_base + (r & 3) + 8 * (r >> 2);
+        e_b[r] = s_par[cl]; e_sc[r] = s_par[p.NB + cl]; e_sf[r] = s_par[2 * p.NB + cl];
+        e_sl[r] = s_par[3 * p.NB + cl]; e_g[r] = s_par[4 * p.NB + cl];
+    }
+    const int jj = j0 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = cb * p.NB + col_base + (r & 3) + 8 * (r >> 2);
         if (co >= p.K) continue;
-        const float b = p.bias[co], sc = p.scale[co], sf = p.shift[co];
-        const float slope = p.act_param ? p.act_param[p.act_pc ? co : 0] : 0.f;
-        const float gt = p.gate ? p.gate[(size_t)n * p.K + co] : 1.f;
         const size_t chan = ((size_t)n * p.K + co) * OHW;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int jj = j0 + j;
             const int ow = jj * p.w_nphase + g;
             const bool col_ok = jj < p.w_nout[g];
 #pragma unroll
@@ -312,16 +359,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                 const int i = i0 + wm * TPG + t;
                 if (i >= p.h_nout[a] || !col_ok) continue;
                 const int oh = i * p.h_nphase + a;
-                float v = acc[g][t][r] + b;
-                if (p.act_first) v = apply_act(v, p.act, slope) * sc + sf;
-                else             v = apply_act(v * sc + sf, p.act, slope);
-                v *= gt;
+                float v = acc[g][t][r] + e_b[r];
+                if (p.act_first) v = apply_act(v, p.act, e_sl[r]) * e_sc[r] + e_sf[r];
+                else             v = apply_act(v * e_sc[r] + e_sf[r], p.act, e_sl[r]);
+                v *= e_g[r];
                 const size_t o = chan + (size_t)oh * p.OW + ow;
                 if (p.residual) v += p.residual[o];
                 if (!ABLATE(4) || v == 123.456f) p.out[o] = v;
             }
         }
     }
+    STAMP(7);                      // epilogue
+#ifdef UNETMI_ABLATE
+    if (p.stamps && threadIdx.x == 0) atomicAdd(&p.stamps[8], 1ull);
+#endif
 }
 
 template <int NG, int TPG, int WM, int WN, bool TWO, int NTW0, int NTW1>

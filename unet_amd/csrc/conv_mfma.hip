@@ -25,7 +25,9 @@ namespace unetmi {
 
 #ifdef UNETMI_ABLATE
 int g_ablate = 0;
+unsigned long long* g_stamps = nullptr;
 #endif
+int g_xcd_remap = -1;   // -1: per-layer default; 0/1: forced (developer probe)
 
 static unsigned magic_u32(int d) {
     return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d);
@@ -56,10 +58,12 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
     p.w_colmin = pl.w_colmin;
     p.ci_chunk = pl.ci_chunk; p.nchunk = pl.nchunk; p.NB = pl.NB; p.nco_blk = pl.nco_blk; p.TI = pl.TI;
     p.nrows = pl.nrows; p.ncols = pl.ncols; p.plane = pl.plane;
-    p.in_tile_floats = pl.in_tile_floats; p.njt = pl.njt;
+    p.in_tile_floats = pl.in_tile_floats; p.w_tile_floats = pl.w_tile_floats; p.njt = pl.njt;
     p.magic_ncols = magic_u32(pl.ncols); p.magic_nrows = magic_u32(pl.nrows);
+    p.xcd_remap = g_xcd_remap >= 0 ? g_xcd_remap : 0;
 #ifdef UNETMI_ABLATE
     p.ablate = g_ablate;
+    p.stamps = g_stamps;
 #endif
     if (total == 0) return hipSuccess;
 

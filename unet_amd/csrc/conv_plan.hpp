@@ -189,7 +189,7 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     pl->in_tile_floats = (pl->ci_chunk * pl->plane + 255) & ~255;
     // + one tap of slack: the MFMA loop reads one weight step past the last tap
     pl->w_tile_floats = ((pairs * max_wtaps * 2 * pl->NB / 4 + 255) & ~255) * 4 + 2 * pl->NB;
-    pl->lds_bytes = (size_t)(pl->in_tile_floats + pl->w_tile_floats) * 4;
+    pl->lds_bytes = (size_t)(pl->in_tile_floats + pl->w_tile_floats + 5 * pl->NB) * 4;   // + epilogue params
 
     int max_nj = 0;
     for (int g = 0; g < pl->w.nphase; ++g) max_nj = std::max(max_nj, pl->w.nout[g]);
