@@ -62,7 +62,9 @@ def kernel_variant(d):
         return "direct_conv_kernel"
     ng = d.sw if d.transposed else 1
     wn = 1 if d.K <= 32 else 2
-    return "conv_mfma_kernel<{},{},{},{},{}>".format(ng, 4 // ng, 4 // wn, wn, "true" if d.in_mode == 2 else "false")
+    if d.in_mode == 2:
+        return "conv_mfma_kernel<{},{},{},{},true>".format(ng, 4 // ng, 4 // wn, wn)
+    return "conv_dma_kernel<{},{},{},{}>".format(ng, 4 // ng, 4 // wn, wn)
 
 
 def cpu_baseline(threads):

@@ -46,20 +46,8 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(par, ones.data(), d.K*4*4, hipMemcpyHostToDevice));
     const double macs = d.transposed ? (double)d.N*d.H*d.W*C*d.K*d.kh*d.kw : (double)d.N*d.OH*d.OW*d.K*C*d.kh*d.kw;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    {   // where a workgroup's cycles go (thread 0 of every workgroup, summed)
-        unsigned long long* st; CK(hipMalloc(&st, 9 * 8)); CK(hipMemset(st, 0, 9 * 8));
-        unetmi::g_stamps = st; unetmi::g_ablate = 0; unetmi::g_xcd_remap = 0;
-        CK(unetmi::launch_conv_mfma(d, pl, in0, n1 ? in1 : nullptr, wp, par, par + d.K, par + 2*d.K, par + 3*d.K, nullptr, nullptr, out, 0));
-        CK(hipDeviceSynchronize());
-        unsigned long long h[9]; CK(hipMemcpy(h, st, 72, hipMemcpyDeviceToHost));
-        const char* names[] = {"prologue", "prefetch0 issue", "barrier after compute", "prefetch wait + LDS write",
-                               "barrier after write", "next prefetch issue", "MFMA loops", "epilogue"};
-        double tot = 0; for (int i = 0; i < 8; ++i) tot += (double)h[i];
-        for (int i = 0; i < 8; ++i) printf("  %-28s %10.0f cycles/WG  %5.1f %%\n", names[i], (double)h[i] / h[8], 100.0 * h[i] / tot);
-        printf("  workgroups %llu, %0.f cycles each (100 MHz counter)\n", h[8], tot / h[8]);
-        unetmi::g_stamps = nullptr;
-    }
-    const int flagsets[] = {0, 0, 2|4, 1|2|8};
+    const int flagsets[] = {0, 0, 8, 16, 16|32, 4, 4|16|32, 2};
+    printf("bits: 8 DMA out of range after chunk 0, 16 no DMA issue after chunk 0, 32 no chunk barrier, 4 no stores, 2 no MFMA\n");
     int idx = 0;
     for (int fl : flagsets) {
         unetmi::g_ablate = fl;

@@ -161,8 +161,29 @@ void run(const char* name, int blocks_per_cu, float* out) {
     printf("%-34s %d block/CU: %8.3f ms  %7.1f TFLOP/s\n", name, blocks_per_cu, ms, flops / ms * 1e-9);
 }
 
+template <int MODE>
+void sustained(const char* name, float* out) {
+    // back-to-back launches for ~0.5 s: does the rate hold once the chip has been busy for a while?
+    const int iters = 20000, grid = 512;
+    hipEvent_t e[41]; for (auto& x : e) CK(hipEventCreate(&x));
+    CK(hipEventRecord(e[0], 0));
+    for (int l = 0; l < 40; ++l) {
+        for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(probe<MODE>, dim3(grid), dim3(256), 0, 0, out, iters, 65);
+        CK(hipEventRecord(e[l + 1], 0));
+    }
+    CK(hipEventSynchronize(e[40]));
+    printf("%s sustained, TFLOP/s per 3 launches:", name);
+    for (int l = 0; l < 40; l += 3) {
+        float ms; CK(hipEventElapsedTime(&ms, e[l], e[l + 1]));
+        printf(" %.0f", 3.0 * grid * 4 * iters * 4 * 4096.0 / ms * 1e-9);
+    }
+    printf("\n");
+}
+
 int main() {
     float* out; CK(hipMalloc(&out, 256 * 8 * 256 * 4));
+    sustained<0>("bare MFMA", out);
+    sustained<7>("ping-pong LDS operands", out);
     for (int b = 1; b <= 2; ++b) {
         run<0>("bare 4x MFMA", b, out);
         run<1>("LDS operands one step ahead", b, out);

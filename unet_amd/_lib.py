@@ -32,8 +32,13 @@ class ConvDesc(ctypes.Structure):
         "act_param_per_channel", "has_gate", "has_residual")] + [("reserved", ctypes.c_int32 * 3)]
 
 
+E_BAD_DESC, E_BAD_ARG, E_HIP, E_UNSUPPORTED = -1, -2, -3, -4
+
+
 class UnetmiError(RuntimeError):
-    pass
+    def __init__(self, message, code=0):
+        super().__init__(message)
+        self.code = code
 
 
 def _load():
@@ -69,4 +74,4 @@ def last_error():
 
 def check(code, what):
     if code != 0:
-        raise UnetmiError("{} failed ({}): {}".format(what, code, last_error()))
+        raise UnetmiError("{} failed ({}): {}".format(what, code, last_error()), code)

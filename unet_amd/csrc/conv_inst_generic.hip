@@ -1,17 +1,29 @@
-// Generic kernels: tap geometry walked at run time (any kernel size / dilation),
-// and the two-loads-per-element forms (skip add, concat straddling a chunk).
-#include "conv_kernel.hpp"
+// Run-time-geometry kernels: the register-staged kernel with two loads per input
+// element (skip add; concat whose chunks straddle the two sources) and without, and
+// the double-buffered DMA kernel with its tap walk at run time (any kernel size / dilation).
+#include "conv_dma_kernel.hpp"
 
 namespace unetmi {
 
-bool launch_conv_generic(int ng, int wn, bool two, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p) {
+bool launch_conv_staged(int ng, int wn, bool two, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p) {
 #define UNETMI_GEN(NG_, WN_, TWO_)                                                          \
     if (ng == NG_ && wn == WN_ && two == TWO_) {                                            \
-        launch_conv_variant<NG_, 4 / NG_, 4 / WN_, WN_, TWO_, 0, 0>(grid, lds, s, p);        \
+        launch_conv_variant<NG_, 4, 4 / WN_, WN_, TWO_, 0, 0>(grid, lds, s, p);        \
         return true;                                                                        \
     }
-    UNETMI_GEN(1, 1, false) UNETMI_GEN(1, 2, false) UNETMI_GEN(2, 1, false) UNETMI_GEN(2, 2, false)
-    UNETMI_GEN(1, 1, true)  UNETMI_GEN(1, 2, true)  UNETMI_GEN(2, 1, true)  UNETMI_GEN(2, 2, true)
+    UNETMI_GEN(1, 1, true)  UNETMI_GEN(1, 2, true)      // one column phase only: 128 accumulator
+                                                       // registers leave no room for register staging
+#undef UNETMI_GEN
+    return false;
+}
+
+bool launch_conv_dma_generic(int ng, int wn, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p) {
+#define UNETMI_GEN(NG_, WN_)                                                                \
+    if (ng == NG_ && wn == WN_) {                                                           \
+        launch_dma_variant<NG_, 4, 4 / WN_, WN_, 0, 0>(grid, lds, s, p);               \
+        return true;                                                                        \
+    }
+    UNETMI_GEN(1, 1) UNETMI_GEN(1, 2) UNETMI_GEN(2, 1) UNETMI_GEN(2, 2)
 #undef UNETMI_GEN
     return false;
 }

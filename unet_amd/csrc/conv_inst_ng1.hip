@@ -1,13 +1,13 @@
 // Kernels with the tap row unrolled (1, 3, 5 or 7 taps along time), one column phase:
 // every plain convolution and the transposed ones with time stride 1.
-#include "conv_kernel.hpp"
+#include "conv_dma_kernel.hpp"
 
 namespace unetmi {
 
 bool launch_conv_ng1(int wn, int ntw0, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p) {
 #define UNETMI_NG1(WN_, NTW_)                                                               \
     if (wn == WN_ && ntw0 == NTW_) {                                                        \
-        launch_conv_variant<1, 4, 4 / WN_, WN_, false, NTW_, 0>(grid, lds, s, p);            \
+        launch_dma_variant<1, 4, 4 / WN_, WN_, NTW_, 0>(grid, lds, s, p);            \
         return true;                                                                        \
     }
     UNETMI_NG1(2, 1) UNETMI_NG1(2, 3) UNETMI_NG1(2, 5) UNETMI_NG1(2, 7)

@@ -1,13 +1,13 @@
 // Kernels for transposed convolutions with time stride 2: two column phases whose
 // tap rows (kw = 3 -> 1 and 2 taps, kw = 5 -> 3 and 2 taps) are unrolled.
-#include "conv_kernel.hpp"
+#include "conv_dma_kernel.hpp"
 
 namespace unetmi {
 
 bool launch_conv_ng2(int wn, int ntw0, int ntw1, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p) {
 #define UNETMI_NG2(WN_, A_, B_)                                                             \
     if (wn == WN_ && ntw0 == A_ && ntw1 == B_) {                                            \
-        launch_conv_variant<2, 2, 4 / WN_, WN_, false, A_, B_>(grid, lds, s, p);             \
+        launch_dma_variant<2, 4, 4 / WN_, WN_, A_, B_>(grid, lds, s, p);             \
         return true;                                                                        \
     }
     UNETMI_NG2(2, 1, 2) UNETMI_NG2(2, 3, 2) UNETMI_NG2(1, 1, 2) UNETMI_NG2(1, 3, 2)

@@ -72,9 +72,12 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 // reads are base-register + immediate.  NTW = 0 selects the generic form, where a
 // row is a single tap and the walk also steps the column at run time.
 // ---------------------------------------------------------------------------------
-template <int TPG, int NTW, int ROWS, int NB>
+struct NoSide { __device__ __forceinline__ void operator()() const {} };
+
+template <int TPG, int NTW, int ROWS, int NB, class Side>
 __device__ __forceinline__ void mfma_rows(f32x16 (&acc)[TPG], float (&a)[2], float (&b)[2][TPG],
-                                          const float* wp, const float* const (&rows)[ROWS + 1][TPG]) {
+                                          const float* wp, const float* const (&rows)[ROWS + 1][TPG],
+                                          Side& side) {
     constexpr int NT = ROWS * NTW;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -92,13 +95,14 @@ __device__ __forceinline__ void mfma_rows(f32x16 (&acc)[TPG], float (&a)[2], flo
             if (TPG == 4 && t == 2) b[nxt][3] = rows[nr][3][nc];
             __builtin_amdgcn_sched_barrier(0);
         }
+        side();      // one piece of staging work per tap, issued in the shadow of the MFMAs above
     }
 }
 
-template <int TPG, int NTW, int NB>
+template <int TPG, int NTW, int NB, class Side>
 __device__ __forceinline__ void group_mfma(f32x16 (&acc)[TPG], const float* s_in, const float* wp,
                                            const int (&ib)[TPG], int cpc, int nth, int ntw_rt,
-                                           const ConvArgs& p) {
+                                           const ConvArgs& p, Side& side) {
     constexpr bool GENERIC = NTW == 0;
     constexpr int NTWE = GENERIC ? 1 : NTW;
     const int R = ABLATE(2) ? 0 : (GENERIC ? cpc * nth * ntw_rt : cpc * nth);
@@ -132,7 +136,7 @@ __device__ __forceinline__ void group_mfma(f32x16 (&acc)[TPG], const float* s_in
         const int d2 = (r + 2 < R) ? advance() : 0;            // past the end: re-read the last row
 #pragma unroll
         for (int t = 0; t < TPG; ++t) { rp[1][t] = rp[0][t] + d1; rp[2][t] = rp[1][t] + d2; }
-        mfma_rows<TPG, NTWE, 2, NB>(acc, a, b, wp, rp);
+        mfma_rows<TPG, NTWE, 2, NB>(acc, a, b, wp, rp, side);
         wp += 2 * NTWE * 2 * NB;
 #pragma unroll
         for (int t = 0; t < TPG; ++t) rp[0][t] = rp[2][t];
@@ -141,10 +145,138 @@ __device__ __forceinline__ void group_mfma(f32x16 (&acc)[TPG], const float* s_in
         const float* last[2][TPG];
 #pragma unroll
         for (int t = 0; t < TPG; ++t) { last[0][t] = rp[0][t]; last[1][t] = rp[0][t]; }
-        mfma_rows<TPG, NTWE, 1, NB>(acc, a, b, wp, last);
+        mfma_rows<TPG, NTWE, 1, NB>(acc, a, b, wp, last, side);
     }
 }
 
+
+// Two column phases (transposed conv with time stride 2) walked together: per tap row,
+// the NTW0 taps of phase 0 then the NTW1 taps of phase 1, each on its own accumulators.
+// One loop and one operand pipeline instead of two half-length ones.
+template <int TPG, int NTW0, int NTW1, int ROWS, int NB, class Side>
+__device__ __forceinline__ void mfma_rows2(f32x16 (&acc0)[TPG], f32x16 (&acc1)[TPG], float (&a)[2],
+                                           float (&b)[2][TPG], const float* wp0, const float* wp1,
+                                           const float* const (&rows0)[ROWS + 1][TPG],
+                                           const float* const (&rows1)[ROWS + 1][TPG], Side& side) {
+    constexpr int PR = NTW0 + NTW1;
+    constexpr int NT = ROWS * PR;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        const bool g = (i % PR) >= NTW0;
+        const int nrow = (i + 1) / PR, nk = (i + 1) % PR;
+        const bool ng = nk >= NTW0;
+        const int nc = ng ? nk - NTW0 : nk;
+        const float* wnext = ng ? wp1 + (nrow * NTW1 + nc) * 2 * NB : wp0 + (nrow * NTW0 + nc) * 2 * NB;
+        f32x16 (&acc)[TPG] = g ? acc1 : acc0;
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur], b[cur][t], acc[t], 0, 0, 0);
+            if (t == 0) {
+                a[nxt] = wnext[0];
+                b[nxt][0] = (ng ? rows1 : rows0)[nrow][0][nc];
+                if (TPG == 2) b[nxt][1] = (ng ? rows1 : rows0)[nrow][1][nc];
+            }
+            if (TPG == 4 && t == 1) {
+                b[nxt][1] = (ng ? rows1 : rows0)[nrow][1][nc];
+                b[nxt][2] = (ng ? rows1 : rows0)[nrow][2][nc];
+            }
+            if (TPG == 4 && t == 2) b[nxt][3] = (ng ? rows1 : rows0)[nrow][3][nc];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        side();
+    }
+}
+
+template <int TPG, int NTW0, int NTW1, int NB, class Side>
+__device__ __forceinline__ void group_mfma2(f32x16 (&acc0)[TPG], f32x16 (&acc1)[TPG], const float* s_in,
+                                            const float* wp0, const int (&ib0)[TPG], int phase_shift,
+                                            int cpc, int nth, const ConvArgs& p, Side& side) {
+    const int R = ABLATE(2) ? 0 : cpc * nth;
+    if (R == 0) return;
+    const float* wp1 = wp0 + R * NTW0 * 2 * NB;               // phase 1's weights follow phase 0's
+    const int row_stride = p.h_tap_step * p.ncols;
+    const int pair_wrap = 2 * p.plane - nth * row_stride;
+    int th = 0;
+    auto advance = [&]() -> int {
+        ++th;
+        int d = row_stride;
+        if (th == nth) { th = 0; d += pair_wrap; }
+        return d;
+    };
+    const float* rp0[3][TPG];
+    const float* rp1[3][TPG];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) { rp0[0][t] = s_in + ib0[t]; rp1[0][t] = rp0[0][t] + phase_shift; }
+    float a[2], b[2][TPG];
+    a[0] = wp0[0];
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) b[0][t] = rp0[0][t][0];
+    int r = 0;
+    for (; r + 2 <= R; r += 2) {
+        const int d1 = advance();
+        const int d2 = (r + 2 < R) ? advance() : 0;
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) {
+            rp0[1][t] = rp0[0][t] + d1; rp0[2][t] = rp0[1][t] + d2;
+            rp1[1][t] = rp1[0][t] + d1; rp1[2][t] = rp1[1][t] + d2;
+        }
+        mfma_rows2<TPG, NTW0, NTW1, 2, NB>(acc0, acc1, a, b, wp0, wp1, rp0, rp1, side);
+        wp0 += 2 * NTW0 * 2 * NB;
+        wp1 += 2 * NTW1 * 2 * NB;
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) { rp0[0][t] = rp0[2][t]; rp1[0][t] = rp1[2][t]; }
+    }
+    if (r < R) {
+        const float* l0[2][TPG];
+        const float* l1[2][TPG];
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) { l0[0][t] = l0[1][t] = rp0[0][t]; l1[0][t] = l1[1][t] = rp1[0][t]; }
+        mfma_rows2<TPG, NTW0, NTW1, 1, NB>(acc0, acc1, a, b, wp0, wp1, l0, l1, side);
+    }
+}
+
+// Fused epilogue: bias, BatchNorm affine and activation (either order), gate, residual,
+// store.  Lane = one time column, register = one output channel (MFMA C/D layout).
+template <int NG, int TPG>
+__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NG][TPG], const ConvArgs& p,
+                                              const float* s_par, int n, int cb, int a, int i0, int j0,
+                                              int wm, int wn, int half, int j) {
+    const int col_base = wn * 32 + 4 * half;          // this lane's first channel inside the block
+    const size_t OHW = (size_t)p.OH * p.OW;
+    float e_b[16], e_sc[16], e_sf[16], e_sl[16], e_g[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cl = col_base + (r & 3) + 8 * (r >> 2);
+        e_b[r] = s_par[cl]; e_sc[r] = s_par[p.NB + cl]; e_sf[r] = s_par[2 * p.NB + cl];
+        e_sl[r] = s_par[3 * p.NB + cl]; e_g[r] = s_par[4 * p.NB + cl];
+    }
+    const int jj = j0 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = cb * p.NB + col_base + (r & 3) + 8 * (r >> 2);
+        if (co >= p.K) continue;
+        const size_t chan = ((size_t)n * p.K + co) * OHW;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int ow = jj * p.w_nphase + g;
+            const bool col_ok = jj < p.w_nout[g];
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) {
+                const int i = i0 + wm * TPG + t;
+                if (i >= p.h_nout[a] || !col_ok) continue;
+                const int oh = i * p.h_nphase + a;
+                float v = acc[g][t][r] + e_b[r];
+                if (p.act_first) v = apply_act(v, p.act, e_sl[r]) * e_sc[r] + e_sf[r];
+                else             v = apply_act(v * e_sc[r] + e_sf[r], p.act, e_sl[r]);
+                v *= e_g[r];
+                const size_t o = chan + (size_t)oh * p.OW + ow;
+                if (p.residual) v += p.residual[o];
+                if (!ABLATE(4) || v == 123.456f) p.out[o] = v;
+            }
+        }
+    }
+}
 
 template <int NG, int TPG, int WM, int WN, bool TWO, int NTW0, int NTW1>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
@@ -325,50 +457,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         // ---- MFMA over (column phase; channel pair x tap row x tap col) -------------
         {
             const float* wp = s_w + wlane;
-            group_mfma<TPG, NTW0, 32 * WN>(acc[0], s_in, wp, ib[0], cpc, nth, p.w_ntap[0], p);
+            NoSide none;
+            group_mfma<TPG, NTW0, 32 * WN>(acc[0], s_in, wp, ib[0], cpc, nth, p.w_ntap[0], p, none);
             if (NG == 2) {
                 wp += cpc * nth * p.w_ntap[0] * 2 * p.NB;
-                group_mfma<TPG, NTW1, 32 * WN>(acc[NG - 1], s_in, wp, ib[NG - 1], cpc, nth, p.w_ntap[1], p);
+                group_mfma<TPG, NTW1, 32 * WN>(acc[NG - 1], s_in, wp, ib[NG - 1], cpc, nth, p.w_ntap[1], p, none);
             }
         }
     }
 
     STAMP(6);                      // MFMA loops (all chunks)
     // ---- epilogue ---------------------------------------------------------------
-    const int col_base = wn * 32 + 4 * half;          // this lane's first channel inside the block
-    const size_t OHW = (size_t)p.OH * p.OW;
-    float e_b[16], e_sc[16], e_sf[16], e_sl[16], e_g[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int cl = col_base + (r & 3) + 8 * (r >> 2);
-        e_b[r] = s_par[cl]; e_sc[r] = s_par[p.NB + cl]; e_sf[r] = s_par[2 * p.NB + cl];
-        e_sl[r] = s_par[3 * p.NB + cl]; e_g[r] = s_par[4 * p.NB + cl];
-    }
-    const int jj = j0 + j;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = cb * p.NB + col_base + (r & 3) + 8 * (r >> 2);
-        if (co >= p.K) continue;
-        const size_t chan = ((size_t)n * p.K + co) * OHW;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int ow = jj * p.w_nphase + g;
-            const bool col_ok = jj < p.w_nout[g];
-#pragma unroll
-            for (int t = 0; t < TPG; ++t) {
-                const int i = i0 + wm * TPG + t;
-                if (i >= p.h_nout[a] || !col_ok) continue;
-                const int oh = i * p.h_nphase + a;
-                float v = acc[g][t][r] + e_b[r];
-                if (p.act_first) v = apply_act(v, p.act, e_sl[r]) * e_sc[r] + e_sf[r];
-                else             v = apply_act(v * e_sc[r] + e_sf[r], p.act, e_sl[r]);
-                v *= e_g[r];
-                const size_t o = chan + (size_t)oh * p.OW + ow;
-                if (p.residual) v += p.residual[o];
-                if (!ABLATE(4) || v == 123.456f) p.out[o] = v;
-            }
-        }
-    }
+    conv_epilogue<NG, TPG>(acc, p, s_par, n, cb, a, i0, j0, wm, wn, half, j);
     STAMP(7);                      // epilogue
 #ifdef UNETMI_ABLATE
     if (p.stamps && threadIdx.x == 0) atomicAdd(&p.stamps[8], 1ull);
@@ -382,7 +482,8 @@ inline void launch_conv_variant(unsigned grid, size_t lds, hipStream_t stream, c
 }
 
 // Instantiation units.  Each returns false when it holds no kernel for the request.
-bool launch_conv_generic(int ng, int wn, bool two, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
+bool launch_conv_staged(int ng, int wn, bool two, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
+bool launch_conv_dma_generic(int ng, int wn, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
 bool launch_conv_ng1(int wn, int ntw0, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
 bool launch_conv_ng2(int wn, int ntw0, int ntw1, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
 

@@ -27,6 +27,7 @@ namespace unetmi {
 int g_ablate = 0;
 unsigned long long* g_stamps = nullptr;
 #endif
+int g_force_staged = 0;  // 1: always use the register-staged kernel (developer probe)
 int g_xcd_remap = -1;   // -1: per-layer default; 0/1: forced (developer probe)
 
 static unsigned magic_u32(int d) {
@@ -67,16 +68,19 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
 #endif
     if (total == 0) return hipSuccess;
 
-    const size_t lds = pl.lds_bytes;
     // two loads per input element: the skip add, or a concat whose channel chunks straddle C0
-    const bool two = d.in_mode == UNETMI_IN_ADD ||
-                     (d.in_mode == UNETMI_IN_CONCAT && d.C0 % pl.ci_chunk != 0);
+    const bool two = needs_two_loads(d, pl);
     bool done = false;
-    if (!two && pl.w.tap_step == 1) {      // unrolled tap rows with immediate LDS offsets
-        if (pl.NG == 1) done = launch_conv_ng1(pl.WN, pl.w.ntap[0], total, lds, stream, p);
-        else            done = launch_conv_ng2(pl.WN, pl.w.ntap[0], pl.w.ntap[1], total, lds, stream, p);
+    if (two || g_force_staged) {
+        done = launch_conv_staged(pl.NG, pl.WN, true, total, pl.lds_bytes, stream, p);
+    } else {
+        const size_t lds = pl.lds_bytes_dma;
+        if (pl.w.tap_step == 1) {          // unrolled tap rows with immediate LDS offsets
+            if (pl.NG == 1) done = launch_conv_ng1(pl.WN, pl.w.ntap[0], total, lds, stream, p);
+            else            done = launch_conv_ng2(pl.WN, pl.w.ntap[0], pl.w.ntap[1], total, lds, stream, p);
+        }
+        if (!done) done = launch_conv_dma_generic(pl.NG, pl.WN, total, lds, stream, p);
     }
-    if (!done) done = launch_conv_generic(pl.NG, pl.WN, two, total, lds, stream, p);
     if (!done) return hipErrorInvalidConfiguration;
     return hipGetLastError();
 }

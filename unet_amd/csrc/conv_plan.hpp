@@ -16,7 +16,7 @@ namespace unetmi {
 constexpr int kMaxPhase = 4;      // output phases per axis = stride of a transposed conv
 constexpr int kWaves = 4;         // waves per workgroup
 constexpr int kTileJ = 32;        // output columns of one MFMA tile (the 32 of 32x32x2)
-constexpr int kLdsBudget = 64 * 1024;   // staged images; the kernel may add < 1 KB of slack
+constexpr int kLdsBudget = 38 * 1024;   // one staged (input patch + weights) image; the main kernel holds two
 constexpr int kMaxInSlots = 24;   // input-patch floats a thread prefetches per chunk (x256 threads)
 constexpr int kMaxW4Slots = 10;   // weight float4s a thread prefetches per chunk
 constexpr int kMaxTaps = 64;      // taps of one (row phase, column phase) pair
@@ -78,7 +78,7 @@ struct ConvPlan {
     int NB = 64;           // output channels per workgroup (32 or 64)
     int nco_blk = 1;
     int WM = 2, WN = 2;    // wave grid inside the workgroup (WM*WN = 4)
-    int NG = 1, TPG = 4;   // per wave: NG column-phase groups x TPG rows = 4 MFMA tiles
+    int NG = 1, TPG = 4;   // per wave: NG column-phase groups x TPG rows of 32x32 accumulator tiles
     int TI = 8;            // phase-index rows per workgroup = WM * TPG
     int nrows = 1, ncols = 1, pitch = 1, plane = 1;   // LDS input tile (floats)
     int w_colmin = 0;      // smallest column offset over the column phases
@@ -86,7 +86,7 @@ struct ConvPlan {
     size_t w_phase_off[kMaxPhase] = {0, 0, 0, 0};   // float offset of each row phase's image
     size_t packed_floats = 0;
     int in_tile_floats = 0, w_tile_floats = 0;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, lds_bytes_dma = 0;
     int nit[kMaxPhase] = {0, 0, 0, 0};        // row tiles per row phase
     int njt = 1;                               // column tiles
     // direct (vector-ALU) family for the thin layers; see direct_conv.hip
@@ -131,7 +131,7 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     pl->NB = (d.K <= 32) ? 32 : 64;
     pl->nco_blk = (d.K + pl->NB - 1) / pl->NB;
     pl->WN = pl->NB / 32; pl->WM = kWaves / pl->WN;
-    pl->NG = pl->w.nphase; pl->TPG = 4 / pl->NG;
+    pl->NG = pl->w.nphase; pl->TPG = 4;
     pl->TI = pl->WM * pl->TPG;
 
     int max_nth = 0;
@@ -161,13 +161,18 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     }
     // channels per LDS pass: the most that fits next to their weights
     const int cpad = (pl->Ctot + 1) & ~1;
-    const size_t per_pair = (size_t)2 * pl->plane * 4 + (size_t)max_wtaps * 2 * pl->NB * 4;
-    int max_pairs = (int)std::min<size_t>((size_t)kLdsBudget / std::max<size_t>(per_pair, 1), 16);
-    max_pairs = std::min(max_pairs, cpad / 2);
-    // what one workgroup can hold in registers while the previous chunk computes
-    max_pairs = std::min(max_pairs, kMaxInSlots * 256 / (2 * pl->plane));
-    if (max_wtaps > 0) max_pairs = std::min(max_pairs, kMaxW4Slots * 1024 / (max_wtaps * 2 * pl->NB));
-    if (max_pairs < 1) { *err = "one channel pair does not fit in LDS for this geometry"; return false; }
+    auto in_floats = [&](int prs) { return (2 * prs * pl->plane + 255) & ~255; };
+    // + one tap of slack: the MFMA loop reads one weight step past the last tap
+    auto w_floats = [&](int prs) { return ((prs * max_wtaps * 2 * pl->NB / 4 + 255) & ~255) * 4 + 2 * pl->NB; };
+    int max_pairs = std::min(16, cpad / 2);
+    while (max_pairs > 1 && (in_floats(max_pairs) + w_floats(max_pairs)) * 4 > kLdsBudget) --max_pairs;
+    // what the register-staged kernel can hold per thread while the previous chunk computes
+    max_pairs = std::min(max_pairs, std::max(1, kMaxInSlots * 256 / (2 * pl->plane)));
+    if (max_wtaps > 0) max_pairs = std::min(max_pairs, std::max(1, kMaxW4Slots * 1024 / (max_wtaps * 2 * pl->NB)));
+    if ((in_floats(max_pairs) + w_floats(max_pairs)) * 4 > kLdsBudget || 2 * max_pairs * pl->plane > kMaxInSlots * 256 ||
+        max_pairs * max_wtaps * 2 * pl->NB > kMaxW4Slots * 1024) {
+        *err = "one channel pair does not fit in LDS for this geometry"; return false;
+    }
     // among chunk sizes in (max/2, max], take the one that pads the channel
     // count the least (padding is MFMA work on zeros); ties go to the larger
     int pairs = max_pairs, best_total = 1 << 30;
@@ -186,16 +191,22 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     }
     pl->packed_floats = std::max<size_t>(off, 4);
     // both LDS images are padded to whole 256-thread slots so staging needs no per-lane guard
-    pl->in_tile_floats = (pl->ci_chunk * pl->plane + 255) & ~255;
-    // + one tap of slack: the MFMA loop reads one weight step past the last tap
-    pl->w_tile_floats = ((pairs * max_wtaps * 2 * pl->NB / 4 + 255) & ~255) * 4 + 2 * pl->NB;
-    pl->lds_bytes = (size_t)(pl->in_tile_floats + pl->w_tile_floats + 5 * pl->NB) * 4;   // + epilogue params
+    pl->in_tile_floats = in_floats(pairs);
+    pl->w_tile_floats = w_floats(pairs);
+    pl->lds_bytes = (size_t)(pl->in_tile_floats + pl->w_tile_floats + 5 * pl->NB) * 4;          // register-staged kernel
+    pl->lds_bytes_dma = (size_t)(2 * (pl->in_tile_floats + pl->w_tile_floats) + 5 * pl->NB) * 4; // double-buffered kernel
 
     int max_nj = 0;
     for (int g = 0; g < pl->w.nphase; ++g) max_nj = std::max(max_nj, pl->w.nout[g]);
     pl->njt = (max_nj + kTileJ - 1) / kTileJ;
     for (int a = 0; a < pl->h.nphase; ++a) pl->nit[a] = (pl->h.nout[a] + pl->TI - 1) / pl->TI;
     return true;
+}
+
+// Two loads per input element are needed for the skip add and for a concat whose
+// channel chunks straddle the boundary between the two sources.
+inline bool needs_two_loads(const UnetmiConvDesc& d, const ConvPlan& pl) {
+    return d.in_mode == UNETMI_IN_ADD || (d.in_mode == UNETMI_IN_CONCAT && d.C0 % pl.ci_chunk != 0);
 }
 
 }  // namespace unetmi

@@ -108,7 +108,11 @@ int unetmi_conv2d_fwd(const UnetmiConvDesc* d, const float* in0, const float* in
     if ((d->has_gate != 0) != (gate != nullptr)) return fail(UNETMI_E_BAD_ARG, "gate pointer vs has_gate");
     if ((d->has_residual != 0) != (residual != nullptr))
         return fail(UNETMI_E_BAD_ARG, "residual pointer vs has_residual");
-    if (pl.lds_bytes > 67 * 1024) return fail(UNETMI_E_UNSUPPORTED, "LDS tile exceeds 67 KB");
+    if (pl.lds_bytes_dma > 80 * 1024) return fail(UNETMI_E_UNSUPPORTED, "LDS images exceed 80 KB");
+    if (!pl.direct && pl.NG == 2 && needs_two_loads(*d, pl))
+        return fail(UNETMI_E_UNSUPPORTED,
+                    "two-source input (add, or concat with C0 not a multiple of the channel chunk) on a "
+                    "time-stride-2 transposed conv: combine the inputs first");
     const hipError_t e = (pl.direct ? launch_direct_conv : launch_conv_mfma)(*d, pl, in0, in1, wpacked, bias, scale, shift, act_param,
                                           gate, residual, out, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(UNETMI_E_HIP, std::string("conv launch: ") + hipGetErrorString(e));

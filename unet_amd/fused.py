@@ -154,9 +154,19 @@ class FusedConv:
         if cin != self.conv.in_channels:
             raise RuntimeError("expected {} input channels, got {}".format(self.conv.in_channels, cin))
         if epilogue:
-            return conv2d_fwd(x, x2, st["wpacked"], st["bias"], st["scale"], st["shift"],
+            try:
+                return conv2d_fwd(x, x2, st["wpacked"], st["bias"], st["scale"], st["shift"],
+                                  st["act_param"], gate, residual, st["geom"],
+                                  [st["transposed"], mode, st["act"], int(self.act_first)])
+            except _lib.UnetmiError as e:
+                if e.code != _lib.E_UNSUPPORTED or x2 is None:
+                    raise
+            # the one shape the kernels do not take two sources for (see unetmi_conv2d_fwd):
+            # form the combined input once, then run the single-source kernel
+            merged = torch.cat([x, x2], dim=1) if mode == _lib.IN_CONCAT else x + x2
+            return conv2d_fwd(merged, None, st["wpacked"], st["bias"], st["scale"], st["shift"],
                               st["act_param"], gate, residual, st["geom"],
-                              [st["transposed"], mode, st["act"], int(self.act_first)])
+                              [st["transposed"], _lib.IN_SINGLE, st["act"], int(self.act_first)])
         ones = torch.ones_like(st["bias"])
         return conv2d_fwd(x, x2, st["wpacked"], st["bias"], ones, torch.zeros_like(ones), None, gate,
                           residual, st["geom"], [st["transposed"], mode, _lib.ACT_NONE, 0])
