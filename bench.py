@@ -14,8 +14,8 @@ cross-sample op); a barrier brackets the timed region and the maximum time
 over ranks is used.
 
 Rank 0 prints ONE JSON line.  "roofline" is for the dominant kernel
-(conv_mfma_kernel<1,4,2,2>: every plain conv and the stride-(s,1) transposed
-convs), from HIP events recorded on the launch stream around each of its
+(conv_dma_kernel<1,4,2,2,...>: every plain conv and the transposed convs
+with time stride 1; its per-kernel-width instantiations are summed), from HIP events recorded on the launch stream around each of its
 launches inside the timed region: algorithmic FLOPs (2 x MACs of the layer)
 / launch time, against the dense fp32 MFMA peak.  "cpu_baseline" times the
 CPU oracle (this repository's restatement of the reference, stock torch CPU
@@ -63,8 +63,8 @@ def kernel_variant(d):
     ng = d.sw if d.transposed else 1
     wn = 1 if d.K <= 32 else 2
     if d.in_mode == 2:
-        return "conv_mfma_kernel<{},{},{},{},true>".format(ng, 4 // ng, 4 // wn, wn)
-    return "conv_dma_kernel<{},{},{},{}>".format(ng, 4 // ng, 4 // wn, wn)
+        return "conv_mfma_kernel<{},4,{},{},true>".format(ng, 4 // wn, wn)
+    return "conv_dma_kernel<{},4,{},{}>".format(ng, 4 // wn, wn)
 
 
 def cpu_baseline(threads):

@@ -57,7 +57,7 @@ struct DmaSide {
 };
 
 template <int NG, int TPG, int WM, int WN, int NTW0, int NTW1>
-__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, NG == 1 ? 3 : 2) void conv_dma_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int buf_floats = p.in_tile_floats + p.w_tile_floats;
     float* s_par = smem + 2 * buf_floats;          // [5][NB]: bias, scale, shift, slope, gate

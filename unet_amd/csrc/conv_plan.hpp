@@ -16,7 +16,9 @@ namespace unetmi {
 constexpr int kMaxPhase = 4;      // output phases per axis = stride of a transposed conv
 constexpr int kWaves = 4;         // waves per workgroup
 constexpr int kTileJ = 32;        // output columns of one MFMA tile (the 32 of 32x32x2)
-constexpr int kLdsBudget = 38 * 1024;   // one staged (input patch + weights) image; the main kernel holds two
+constexpr int kLdsBudget3 = 25 * 1024;  // one staged (input patch + weights) image such that three
+                                       // double-buffered workgroups share a CU's 160 KB ...
+constexpr int kLdsBudget = 38 * 1024;   // ... or two, when a channel pair needs more (or 128 accumulators cap it at two)
 constexpr int kMaxInSlots = 24;   // input-patch floats a thread prefetches per chunk (x256 threads)
 constexpr int kMaxW4Slots = 10;   // weight float4s a thread prefetches per chunk
 constexpr int kMaxTaps = 64;      // taps of one (row phase, column phase) pair
@@ -165,7 +167,8 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     // + one tap of slack: the MFMA loop reads one weight step past the last tap
     auto w_floats = [&](int prs) { return ((prs * max_wtaps * 2 * pl->NB / 4 + 255) & ~255) * 4 + 2 * pl->NB; };
     int max_pairs = std::min(16, cpad / 2);
-    while (max_pairs > 1 && (in_floats(max_pairs) + w_floats(max_pairs)) * 4 > kLdsBudget) --max_pairs;
+    const int budget = (pl->NG == 1 && (in_floats(1) + w_floats(1)) * 4 <= kLdsBudget3) ? kLdsBudget3 : kLdsBudget;
+    while (max_pairs > 1 && (in_floats(max_pairs) + w_floats(max_pairs)) * 4 > budget) --max_pairs;
     // what the register-staged kernel can hold per thread while the previous chunk computes
     max_pairs = std::min(max_pairs, std::max(1, kMaxInSlots * 256 / (2 * pl->plane)));
     if (max_wtaps > 0) max_pairs = std::min(max_pairs, std::max(1, kMaxW4Slots * 1024 / (max_wtaps * 2 * pl->NB)));
