@@ -1,0 +1,143 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports what
+include/unetmi.h declares, descriptor validation, weight packing, drop-in
+module structure, deterministic seeding and the data-parallel sharding."""
+
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from unet_amd import _lib
+    header = open(os.path.join(ROOT, "include", "unetmi.h")).read()
+    declared = set(re.findall(r"\b(unetmi_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), "libunetmi.so does not export " + sym
+    assert set(_lib.EXPORTED_SYMBOLS) == declared
+    assert _lib.lib.unetmi_version() >= 100
+
+
+def test_descriptor_validation_and_error_text():
+    from unet_amd import _lib
+    from unet_amd.ops import make_desc
+    d = make_desc(1, 4, 0, 16, 16, [8, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0], [0, 0, 0, 0])
+    assert _lib.lib.unetmi_conv2d_packed_weight_bytes(ctypes.byref(d)) > 0
+    d.OH += 1                                   # inconsistent output size
+    assert _lib.lib.unetmi_conv2d_packed_weight_bytes(ctypes.byref(d)) == 0
+    assert "output size" in _lib.last_error()
+    d = make_desc(1, 4, 0, 16, 16, [8, 3, 3, 2, 2, 1, 1, 2, 2, 0, 0], [1, 0, 0, 0])
+    assert _lib.lib.unetmi_conv2d_packed_weight_bytes(ctypes.byref(d)) == 0   # stride 2 with dilation 2
+    assert "dilation" in _lib.last_error()
+    # compute entry point rejects null tensors without touching a device
+    d = make_desc(1, 4, 0, 16, 16, [8, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0], [0, 0, 0, 0])
+    rc = _lib.lib.unetmi_conv2d_fwd(ctypes.byref(d), *([None] * 10), None)
+    assert rc == _lib.E_BAD_ARG
+
+
+def test_pack_weights_is_a_permutation_with_zero_padding():
+    from unet_amd.ops import pack_conv_weights
+    for transposed, shape in ((0, (64, 6, 7, 5)), (1, (6, 64, 7, 5))):
+        w = torch.arange(1, 1 + int(np.prod(shape)), dtype=torch.float32).reshape(shape)
+        geom = [64, 7, 5, 2, 2, 3, 2, 1, 1, 0, 0]
+        packed = pack_conv_weights(w, 6, 0, geom, [transposed, 0, 0, 0])
+        nz = packed[packed != 0]
+        assert nz.numel() == w.numel()
+        assert torch.equal(torch.sort(nz).values, torch.sort(w.reshape(-1)).values)
+    # thin layer -> direct kernel image [ci][kh][kpad]; transposed layers are flipped along kh
+    w = torch.arange(1, 1 + 12 * 7, dtype=torch.float32).reshape(12, 1, 7, 1)
+    packed = pack_conv_weights(w, 12, 0, [1, 7, 1, 1, 1, 3, 0, 1, 1, 0, 0], [1, 0, 0, 0])
+    assert packed.numel() == 12 * 7
+    assert torch.equal(packed.reshape(12, 7), w.reshape(12, 7).flip(1))
+
+
+def test_dropin_modules_have_reference_structure():
+    import oracle
+    import unet_amd
+    dev = unet_amd.UNet(*unet_amd.default_unet_blocks(f_dim=8))
+    ref = oracle.UNet(*oracle.default_unet(f_dim=8))
+    assert list(dev.state_dict().keys()) == list(ref.state_dict().keys())
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    assert dev.len_model == 10 and isinstance(dev.encoders, list) and dev.encoders[-1].conv.out_channels == 16
+    for name in ("conv", "bn", "acti", "dropout"):
+        assert hasattr(dev.encoders[0], name)
+    for name in ("transconv", "bn", "acti"):
+        assert hasattr(dev.decoders[0], name)
+    with pytest.raises(Exception, match="unmatched legnth"):
+        unet_amd.UNet(dev.encoders, dev.decoders[:-1])
+    with pytest.raises(Exception, match="unknown normalization"):
+        unet_amd.Encoder(2, 4, (3, 3), 1, norm="GroupNorm")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        dev.eval()(torch.zeros(1, 2, 257, 13))
+
+
+def test_seeding_is_deterministic_and_name_keyed():
+    from unet_amd.seeding import seeded_fill_, uniform01
+    a, b = nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4)), nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4))
+    seeded_fill_(a, seed=5), seeded_fill_(b, seed=5)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    assert not np.array_equal(uniform01("x", 8, 1), uniform01("y", 8, 1))
+    assert np.array_equal(uniform01("x", 8, 1)[:4], uniform01("x", 4, 1))
+    assert (a[1].running_var > 0.49).all()
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import oracle
+from unet_amd.sharding import shard_batch
+from unet_amd.seeding import seeded_fill_, normal
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+net = oracle.UNet(*oracle.default_unet(f_dim=8)).eval()
+seeded_fill_(net, seed=3)                      # every rank regenerates identical weights
+x = normal("shard/x", (5, 2, 257, 13), seed=3)  # 5 utterances over 2 ranks: 3 + 2
+lo, hi = shard_batch(x.shape[0], rank, world)
+with torch.no_grad():
+    mine = net(x[lo:hi])
+    whole = net(x)
+# CPU convolution picks its algorithm per batch size, so rows agree to rounding, not bitwise
+assert (mine - whole[lo:hi]).abs().max().item() <= 1e-5 * whole.abs().max().item(), "shard differs from full batch"
+counts = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+dist.all_gather(counts, torch.tensor([hi - lo]))
+assert sum(int(c) for c in counts) == x.shape[0]
+t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)        # the bench's max-over-ranks timing reduction
+assert t.item() == world
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_batch_sharding_two_ranks_gloo(tmp_path):
+    """N-rank result == rows of the 1-rank result (no collective in the data path)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script), ROOT],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2
+
+
+def test_shard_batch_covers_everything_once():
+    from unet_amd.sharding import shard_batch
+    for total in (0, 1, 5, 64, 257):
+        for world in (1, 2, 3, 8):
+            spans = [shard_batch(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
