@@ -1,0 +1,73 @@
+"""End-to-end parity of the device cRFUNet.UNet20 and DSUNet against the oracle and
+the golden vectors the reference produced."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, load_golden, sample_index
+
+pytestmark = pytest.mark.gpu
+
+
+def _sampled(t, n=2048):
+    flat = torch.view_as_real(t).detach().cpu().reshape(-1)
+    return flat[torch.from_numpy(sample_index(flat.numel(), n))]
+
+
+@pytest.mark.parametrize("T", [29, 125])
+def test_unet20_matches_golden_and_oracle(device, T):
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import uniform
+    ref = oracle.UNet20().eval()
+    unet_amd.seeded_fill_(ref, seed=21)
+    dev = unet_amd.UNet20()
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    ref.T = dev.T = T
+    x = uniform("unet20/x{}".format(T), (1, 14, 257, T), 0.0, 1.0, seed=21)
+    with torch.no_grad():
+        want = ref(x)
+        got = dev.eval().to(device)(x.to(device))
+    assert got.dtype == torch.complex64 and tuple(got.shape) == (1, 4, 4, 1, 1, 257, T)
+    assert_close(got, want, what="UNet20 HIP vs oracle")
+    g = load_golden("unet20_eval_T{}".format(T))
+    assert_close(_sampled(got), torch.from_numpy(g["out_samples"]), what="UNet20 HIP vs golden")
+
+
+def test_unet20_sigmoid_mask_and_batch(device):
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import uniform
+    ref = oracle.UNet20(mask="Sigmoid").eval()
+    unet_amd.seeded_fill_(ref, seed=22)
+    dev = unet_amd.UNet20(mask="Sigmoid")
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    ref.T = dev.T = 13
+    x = uniform("unet20/xb", (3, 14, 257, 13), 0.0, 1.0, seed=22)
+    with torch.no_grad():
+        assert_close(dev.eval().to(device)(x.to(device)), ref(x), what="UNet20 sigmoid")
+
+
+def test_dsunet_matches_golden_and_oracle(device):
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.DSUNet(oracle.dsunet_architecture(45, 8)).eval()
+    unet_amd.seeded_fill_(ref, seed=41)
+    dev = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8))
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    sf = normal("dsunet/sf", (2, 8, 257, 16), seed=41)
+    SV = normal("dsunet/SV", (2, 4, 514), seed=41)
+    ang = uniform("dsunet/theta", (2,), 0.0, 2 * np.pi, seed=41)
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    with torch.no_grad():
+        want = ref(sf, SV, theta)
+        got = dev.eval().to(device)(sf.to(device), SV.to(device), theta.to(device))
+    assert got.dtype == torch.complex64 and tuple(got.shape) == (2, 257, 16)
+    assert_close(got, want, what="DSUNet HIP vs oracle")
+    g = load_golden("dsunet_eval")
+    assert_close(torch.view_as_real(got), torch.from_numpy(g["out"]), what="DSUNet HIP vs golden")
+    X = torch.complex(normal("dsunet/Xr", (2, 257, 16), seed=41), normal("dsunet/Xi", (2, 257, 16), seed=41))
+    assert_close(torch.view_as_real(dev.masking(X.to(device), got)), torch.from_numpy(g["masked"]),
+                 what="CRM output vs golden")

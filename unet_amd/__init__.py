@@ -9,6 +9,10 @@ loudly when it is missing: there is no CPU or eager fallback.
 from . import _lib, ops  # noqa: F401  (loads libunetmi.so, registers torch.ops.unetmi.*)
 from .UNet_m import Encoder, Decoder
 from .UNet import UNet, default_unet_blocks
+from .cRFUNet import UNet20, UNet10
+from .DSUNet import DSUNet
+from .tables import dsunet_architecture
 from .seeding import seeded_fill_
 
-__all__ = ["Encoder", "Decoder", "UNet", "default_unet_blocks", "seeded_fill_"]
+__all__ = ["Encoder", "Decoder", "UNet", "UNet20", "UNet10", "DSUNet", "default_unet_blocks",
+           "dsunet_architecture", "seeded_fill_"]

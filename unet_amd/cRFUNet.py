@@ -1,0 +1,59 @@
+"""Device ``UNet20`` (complex-ratio-filter U-Net) with the reference's constructor
+and ``forward`` (cRFUNet.py:162-324).
+
+Same fused encoder/decoder launches as ``unet_amd.UNet``; the head
+``Conv2d(64, 2*c_out*N, 1)`` + Softplus (or Sigmoid) is one more fused launch
+whose output is written NCHW-contiguous, because the reference then REINTERPRETS
+that buffer as ``[B, N, c_out, 2L_f+1, 2L_t+1, F, T, 2]`` complex (adjacent time
+frames pair up as re/im, cRFUNet.py:320-324) -- reproduced here as the same
+zero-copy reshape + ``view_as_complex`` on the device tensor.
+"""
+
+import torch
+import torch.nn as nn
+
+from .UNet import concat_shell_forward, register_concat_shell
+from .UNet_m import Decoder, Encoder
+from .fused import FusedConv, require_device_tensor
+from .tables import unet20_layers
+
+
+class UNet20(nn.Module):
+    def __init__(self, c_in=4 + 6 + 4, c_out=4, L_t=0, L_f=0, n_target=4, n_feature=12, n_fft=512,
+                 device="cuda:0", print_shape=False, mask="Softplus"):
+        super().__init__()
+        self.print_shape = print_shape
+        self.N, self.C, self.c_out = n_target, c_in, c_out
+        self.L_t, self.L_f = L_t, L_f
+        self.F = int(n_fft / 2 + 1)
+        self.T = 125                      # the reference hard-codes 125 (cRFUNet.py:187); set it per input
+        f_dim = 32
+        enc_rows, dec_rows = unet20_layers(c_in=c_in, c_last=2 * f_dim, f_dim=f_dim)
+        self.linear = nn.Conv2d(2 * f_dim, 2 * c_out * n_target, 1)
+        register_concat_shell(self, [Encoder(*r["args"], **r["kw"]) for r in enc_rows],
+                              [Decoder(*r["args"], **r["kw"]) for r in dec_rows], None, None)
+        self.activation_mask = nn.Sigmoid() if mask == "Sigmoid" else nn.Softplus()
+        self._head = None
+
+    def forward(self, x):
+        require_device_tensor(x, "UNet20")
+        p = concat_shell_forward(self, x)
+        if self._head is None:
+            object.__setattr__(self, "_head", FusedConv(self.linear, None, self.activation_mask))
+        f = self._head(p)                 # [B, 2*c_out*N, F, T], contiguous
+        f = torch.reshape(f, (f.shape[0], self.N, self.c_out, 2 * self.L_f + 1, 2 * self.L_t + 1,
+                              self.F, self.T, 2))
+        return torch.view_as_complex(f)
+
+
+class UNet10(nn.Module):
+    """The reference's ``UNet10`` cannot be constructed: it passes ``padding`` to
+    ``Decoder`` both positionally and by keyword (cRFUNet.py:48-54 against the
+    signature at UNet_m.py:348).  Kept with the same failure so callers see the
+    same ``TypeError``."""
+
+    def __init__(self, c_in=4 + 6 + 4, c_out=4, L_t=0, L_f=0, n_target=4, n_feature=12, n_fft=512,
+                 device="cuda:0", print_shape=False, mask="Softplus"):
+        super().__init__()
+        f = 64
+        Decoder(f, f, (4, 5), (2, 1), (1, 0), padding=(2, 1))   # raises TypeError, as in the reference
