@@ -131,6 +131,39 @@ int unetmi_conv2d_fwd(const UnetmiConvDesc* d,
                       const float* residual,
                       float* out, void* stream);
 
+/* Depthwise (groups = C) convolution, stride 1, 'same' padding 2p = d(k-1); kernel 3x3,
+ * 1x3 or 3x1.  Replaces the first conv of each ResBlock layer
+ *   nn.Conv2d(C, C, (3,3), (1,1), (1,d), (1,d), groups=C)            UNet_m.py:546-548
+ * and, with in2, the torch.add(y, res) in front of a decoder's ResBlock       ResUNet.py:209
+ * in/in2/out: device fp32 [N,C,H,W] (in2 null, or an addend summed into the input on the fly);
+ * weight: device fp32 [C,1,kh,kw] (torch layout); bias: [C] or null. */
+int unetmi_dwconv2d_fwd(int N, int C, int H, int W, int kh, int kw, int ph, int pw, int dh, int dw,
+                        const float* in, const float* in2, const float* weight, const float* bias, float* out,
+                        void* stream);
+
+/* LayerNorm over the FREQUENCY axis of x[N,C,F,T] (biased variance, affine gamma/beta[F]),
+ * written into channels [c_off, c_off+C) of out[N,C_out,F,T].  Replaces
+ *   permute -> nn.LayerNorm(257) on [B,C,T,F] -> permute -> torch.cat       ResUNet.py:165-175, :49, :53
+ * with the two permutes folded into the indexing and the cat into the channel offset. */
+int unetmi_layernorm_f_fwd(int N, int C, int F, int T, int C_out, int c_off, float eps, const float* x,
+                           const float* gamma, const float* beta, float* out, void* stream);
+
+/* out[n,k,f,t] = (tanh(y[n,k,f,t]) + eps) * x[n,k,f,t] with x holding Cx >= K channels of which
+ * the first K are used.  Replaces  mask = tanh(y) + 1e-13 ; output = mask * input[:, :2]
+ *   ResUNet.py:217-219.   y, out: [N,K,F,T]; x: [N,Cx,F,T]; device fp32. */
+int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const float* y, const float* x, float* out,
+                         void* stream);
+
+/* Complex ratio filter / complex mask application over the STFT:
+ *   Y[b,n,c,f,t] = sum_{p<PF, q<PT} Hf[b,n,c,p,q,f,t] * X[b,c,f+p-(PF-1)/2, t+q-(PT-1)/2]   (zero outside)
+ * Hf: complex64 [B,N,C,PF,PT,F,T] (the tensor cRFUNet.UNet20.forward returns, cRFUNet.py:320-324);
+ * X: complex64 [B,C,F,T]; Y: complex64 [B,N,C,F,T]; all passed as interleaved float pairs.
+ * With N = C = PF = PT = 1 it is the complex mask product X * M of CRM.output (DSUNet.py:361-362).
+ * The reference only EMITS the ratio filter; its application has no counterpart there, so this
+ * definition is this library's own (checked against its CPU restatement only). */
+int unetmi_crf_apply(int B, int N, int C, int PF, int PT, int F, int T, const float* Hf, const float* X, float* Y,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,3 +71,68 @@ def test_dsunet_matches_golden_and_oracle(device):
     X = torch.complex(normal("dsunet/Xr", (2, 257, 16), seed=41), normal("dsunet/Xi", (2, 257, 16), seed=41))
     assert_close(torch.view_as_real(dev.masking(X.to(device), got)), torch.from_numpy(g["masked"]),
                  what="CRM output vs golden")
+
+
+def test_resblock_matches_golden_and_oracle(device):
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    ref = oracle.ResBlock(16).eval()
+    unet_amd.seeded_fill_(ref, seed=32)
+    dev = unet_amd.ResBlock(16)
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    x = normal("resblock/x", (2, 16, 9, 40), seed=32)
+    with torch.no_grad():
+        want = ref(x)
+        got = dev.eval().to(device)(x.to(device))
+        assert_close(got, want, what="ResBlock HIP vs oracle")
+        assert_close(got, torch.from_numpy(load_golden("resblock_eval")["out"]), what="ResBlock HIP vs golden")
+        a = normal("resblock/add", (2, 16, 9, 40), seed=33)
+        assert_close(dev(x.to(device), add=a.to(device)), ref(x + a), what="ResBlock(x + add)")
+
+
+def test_resunet_matches_golden_and_oracle(device):
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    ref = oracle.ResUNet().eval()
+    unet_amd.seeded_fill_(ref, seed=31)
+    dev = unet_amd.ResUNet()
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    x = normal("resunet/x", (1, 4, 257, 16), seed=31)
+    with torch.no_grad():
+        want = ref(x)
+        got = dev.eval().to(device)(x.to(device))
+    assert tuple(got.shape) == (1, 2, 257, 16)
+    assert_close(got, want, what="ResUNet HIP vs oracle")
+    assert_close(got, torch.from_numpy(load_golden("resunet_eval")["out"]), what="ResUNet HIP vs golden")
+
+
+def test_pointwise_kernels(device):
+    """LayerNorm over frequency, tanh mask, complex ratio filter (3x3 taps) and the
+    complex-mask product, each against its CPU restatement."""
+    import oracle
+    from unet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 257, 37, generator=g)
+    ln = torch.nn.LayerNorm(257)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(257, generator=g) + 0.5)
+        ln.bias.copy_(torch.randn(257, generator=g) * 0.1)
+        want = ln(x.permute(0, 1, 3, 2)).permute(0, 1, 3, 2)
+    out = torch.zeros(2, 5, 257, 37, device=device)
+    ops.layernorm_f(x.to(device), ln.weight.to(device), ln.bias.to(device), ln.eps, out, 2)
+    assert_close(out[:, 2:], want, what="layernorm over F")
+    assert out[:, :2].abs().max().item() == 0.0
+
+    y, xin = torch.randn(2, 2, 33, 29, generator=g), torch.randn(2, 4, 33, 29, generator=g)
+    assert_close(ops.tanh_mask_mul(y.to(device), xin.to(device), 1e-13), oracle.resunet_mask_apply(y, xin),
+                 what="tanh mask")
+
+    H = torch.complex(torch.randn(2, 3, 4, 3, 3, 17, 23, generator=g), torch.randn(2, 3, 4, 3, 3, 17, 23, generator=g))
+    X = torch.complex(torch.randn(2, 4, 17, 23, generator=g), torch.randn(2, 4, 17, 23, generator=g))
+    assert_close(ops.crf_apply(H.to(device), X.to(device)), oracle.crf_apply(H, X), what="cRF 3x3 taps")
+    M = torch.complex(torch.randn(2, 1, 1, 1, 1, 17, 23, generator=g), torch.randn(2, 1, 1, 1, 1, 17, 23, generator=g))
+    X1 = X[:, :1].contiguous()
+    assert_close(ops.crf_apply(M.to(device), X1.to(device))[:, 0, 0], oracle.crm_apply(X1[:, 0], M[:, 0, 0, 0, 0]),
+                 what="complex mask product")

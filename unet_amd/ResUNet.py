@@ -1,0 +1,110 @@
+"""Device ``ResUNet`` with the reference's constructor and ``forward`` (ResUNet.py:22-220).
+
+What runs where:
+  * input layers: the (1,3) conv over the permuted [B,C,T,F] view is run as a (3,1)
+    conv on the tensor as it is (weight axes swapped), BatchNorm + LeakyReLU in its
+    epilogue; LayerNorm(257) over frequency is one launch per branch that writes
+    straight into its channel range of the 64-channel tensor (no permute, no cat);
+  * encoders / decoders / res-paths: fused conv launches (PReLU + BatchNorm in the
+    epilogue, ``y + res`` read as two inputs), ResBlocks as in ``UNet_m.ResBlock``;
+  * bottleneck: ``nn.LSTM(384, 640, 3, proj_size=384)`` runs as torch's own device
+    LSTM -- the one part of this model that is not a kernel of this library;
+  * output: transposed (3,1) conv to 2 channels, then (tanh(y) + 1e-13) * input[:, :2]
+    as one launch.
+"""
+
+import torch
+import torch.nn as nn
+
+from .UNet_m import Decoder, Encoder, ResBlock
+from .fused import FusedConv, require_device_tensor
+from .ops import layernorm_f, tanh_mask_mul
+
+
+class ResUNet(nn.Module):
+    def __init__(self, c_in=4, c_out=1, n_fft=512, device="cuda:0", output="mapping", print_shape=False, T=125):
+        super().__init__()
+        n_hfft = int(n_fft / 2 + 1)
+        self.print_shape = print_shape
+        self.F, self.T = n_hfft, T
+        C = 64
+        prelu = dict(activation="PReLU")
+        self.layer_data = nn.Sequential(Encoder(c_in - 2, 20, (1, 3), 1, (0, 1), 1), nn.LayerNorm(n_hfft))
+        self.layer_AF = nn.Sequential(Encoder(2, C - 20, (1, 3), 1, (0, 1), 1), nn.LayerNorm(n_hfft))
+
+        def down():
+            return nn.Sequential(Encoder(C, C, (3, 3), (2, 1), (0, 1), **prelu), ResBlock(C))
+
+        def up(pad, opad):
+            return nn.Sequential(ResBlock(C), Decoder(C, C, (4, 1), (2, 1), pad, output_padding=opad, **prelu))
+
+        self.encoders = [ResBlock(C)] + [down() for _ in range(5)] + [
+            Encoder(C, 2 * C, (3, 1), (2, 1), (0, 0), **prelu),
+            Encoder(2 * C, 6 * C, (3, 1), (1, 1), (0, 0), **prelu)]
+        for i, m in enumerate(self.encoders):
+            self.add_module("enc_{}".format(i), m)
+        self.decoders = [
+            Decoder(6 * C, 2 * C, (3, 1), (1, 1), (0, 0), **prelu),
+            Decoder(2 * C, C, (4, 1), (2, 1), (1, 0), output_padding=(1, 0), **prelu),
+            up((1, 0), (1, 0)), up((1, 0), (1, 0)), up((1, 0), (1, 0)), up((0, 0), (0, 0)), up((1, 0), (1, 0)),
+            ResBlock(C)]
+        for i, m in enumerate(self.decoders):
+            self.add_module("dec_{}".format(i), m)
+        self.len_model = len(self.encoders)
+        self.res_paths = [Encoder(w, w, 1, 1, 0, 1, **prelu) for w in [C] * 6 + [2 * C, 6 * C]]
+        for i, m in enumerate(self.res_paths):
+            self.add_module("res_path_{}".format(i), m)
+        self.bottleneck = nn.LSTM(6 * C, 10 * C, 3, batch_first=True, proj_size=6 * C)
+        self.out_layer = nn.ConvTranspose2d(C, 2, (3, 1), stride=1, padding=(1, 0), dilation=1, output_padding=(0, 0))
+        self.last_activation = nn.Tanh()
+        self._in_data = self._in_af = self._out = None
+
+    def _input_branch(self, branch, cache_name, x, out, c_off):
+        fused = getattr(self, cache_name)
+        if fused is None:
+            enc = branch[0]
+            fused = FusedConv(enc.conv, enc.bn, enc.acti, swap_hw=True)
+            object.__setattr__(self, cache_name, fused)
+        ln = branch[1]
+        layernorm_f(fused(x), ln.weight, ln.bias, ln.eps, out, c_off)
+
+    def forward(self, input):
+        require_device_tensor(input, "ResUNet")
+        if self.training:
+            raise NotImplementedError("ResUNet: train-mode forward is not available in this build; call .eval()")
+        B, _, F, T = input.shape
+        x = torch.empty((B, 64, F, T), dtype=torch.float32, device=input.device)
+        self._input_branch(self.layer_data, "_in_data", input[:, :-2].contiguous(), x, 0)
+        self._input_branch(self.layer_AF, "_in_af", input[:, -2:].contiguous(), x, 20)
+
+        res = []
+        for i, enc in enumerate(self.encoders):
+            x = enc(x)
+            if self.print_shape:
+                print("x_{} : {}".format(i, x.shape))
+            res.append(x)
+
+        # [B,C,1,T] -> [B,T,C] -> projected LSTM (torch's device implementation) -> [B,C,1,T]
+        seq = x.reshape(x.shape[0], x.shape[1], x.shape[3]).permute(0, 2, 1)
+        seq = self.bottleneck(seq)[0]
+        y = seq.permute(0, 2, 1).reshape(x.shape[0], x.shape[1], 1, x.shape[3]).contiguous()
+
+        for i, rp in enumerate(self.res_paths):
+            res[i] = rp(res[i])
+
+        for i, dec in enumerate(self.decoders):
+            skip = res[-1 - i]
+            if self.print_shape:
+                print("y {} += r_{} : {}".format(y.shape, i, skip.shape))
+            if isinstance(dec, Decoder):
+                y = dec(y, skip, add=True)                 # y + res read as two kernel inputs
+            elif isinstance(dec, ResBlock):
+                y = dec(y, add=skip)
+            else:                                          # Sequential(ResBlock, Decoder)
+                y = dec[1](dec[0](y, add=skip))
+            if self.print_shape:
+                print("y_{} : {}".format(i, y.shape))
+
+        if self._out is None:
+            object.__setattr__(self, "_out", FusedConv(self.out_layer))
+        return tanh_mask_mul(self._out(y), input.contiguous(), 1e-13)

@@ -12,7 +12,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .fused import FusedConv, require_device_tensor
+from .fused import FusedConv, _pair, require_device_tensor
+from .ops import dwconv2d_fwd
 
 
 def _activation(name, where):
@@ -114,3 +115,51 @@ class Decoder(_FusedBlock):
 
     def forward(self, x, skip=None, add=False):
         return self._run(x, skip, in_mode=(_lib.IN_ADD if add else None) if skip is not None else None)
+
+
+class ResBlock(nn.Module):
+    """Five [depthwise 3x3 dilated along time -> pointwise 1x1 -> PReLU -> BatchNorm]
+    layers, the first replacing x and the others adding to the running value
+    (UNet_m.py:518-563).  One PReLU instance is shared by the five layers, as in the
+    reference, so ``res_{0..4}.2.weight`` alias one tensor.
+
+    Per layer: one depthwise launch (bandwidth-bound) and one fused launch for
+    pointwise conv + bias + PReLU + BatchNorm affine + the running-value add.
+    ``forward(x, add)`` starts from ``x + add`` without forming it (the skip add in
+    front of ResUNet's decoder blocks, ResUNet.py:209)."""
+
+    TIME_DILATIONS = (1, 2, 4, 8, 16)
+
+    def __init__(self, n_channel, norm="BatchNorm2d", dropout=0.0, activation="PReLU"):
+        super().__init__()
+        if norm != "BatchNorm2d":
+            raise Exception("ERROR::ResBlock: unknown nromalization - {}".format(norm))
+        if activation != "PReLU":
+            # the reference's GELU branch never defines the local it then uses (UNet_m.py:530-551)
+            raise Exception("ERROR::ResBlock:Unknown activation type " + str(activation))
+        shared = nn.PReLU()
+        self.layers = []
+        for i, d in enumerate(self.TIME_DILATIONS):
+            layer = nn.Sequential(
+                nn.Conv2d(n_channel, n_channel, (3, 3), (1, 1), padding=(1, d), dilation=(1, d), groups=n_channel),
+                nn.Conv2d(n_channel, n_channel, (1, 1)),
+                shared,
+                nn.BatchNorm2d(n_channel))
+            self.add_module("res_{}".format(i), layer)
+            self.layers.append(layer)
+        self._fused = None
+
+    def forward(self, x, add=None):
+        require_device_tensor(x, "ResBlock")
+        if self.training:
+            raise NotImplementedError("ResBlock: train-mode forward is not available in this build; call .eval()")
+        if self._fused is None:
+            object.__setattr__(self, "_fused", [FusedConv(l[1], l[3], l[2], act_first=True) for l in self.layers])
+        r = None
+        for i, layer in enumerate(self.layers):
+            dw = layer[0]
+            src = x if i == 0 else r
+            t = dwconv2d_fwd(src, add if i == 0 else None, dw.weight, dw.bias, list(_pair(dw.padding)),
+                             list(_pair(dw.dilation)))
+            r = self._fused[i](t, residual=r)        # layer 0 has no running value to add
+        return r

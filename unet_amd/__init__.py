@@ -7,12 +7,13 @@ loudly when it is missing: there is no CPU or eager fallback.
 """
 
 from . import _lib, ops  # noqa: F401  (loads libunetmi.so, registers torch.ops.unetmi.*)
-from .UNet_m import Encoder, Decoder
+from .UNet_m import Encoder, Decoder, ResBlock
 from .UNet import UNet, default_unet_blocks
 from .cRFUNet import UNet20, UNet10
 from .DSUNet import DSUNet
+from .ResUNet import ResUNet
 from .tables import dsunet_architecture
 from .seeding import seeded_fill_
 
-__all__ = ["Encoder", "Decoder", "UNet", "UNet20", "UNet10", "DSUNet", "default_unet_blocks",
+__all__ = ["Encoder", "Decoder", "ResBlock", "UNet", "UNet20", "UNet10", "DSUNet", "ResUNet", "default_unet_blocks",
            "dsunet_architecture", "seeded_fill_"]

@@ -21,6 +21,10 @@ EXPORTED_SYMBOLS = (
     "unetmi_conv2d_packed_weight_bytes",
     "unetmi_conv2d_pack_weights",
     "unetmi_conv2d_fwd",
+    "unetmi_dwconv2d_fwd",
+    "unetmi_layernorm_f_fwd",
+    "unetmi_tanh_mask_mul",
+    "unetmi_crf_apply",
 )
 
 
@@ -60,6 +64,13 @@ def _load():
     lib.unetmi_conv2d_pack_weights.restype = ctypes.c_int
     lib.unetmi_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 10 + [vp]
     lib.unetmi_conv2d_fwd.restype = ctypes.c_int
+    ci, cf = ctypes.c_int, ctypes.c_float
+    lib.unetmi_dwconv2d_fwd.argtypes = [ci] * 10 + [fp] * 5 + [vp]
+    lib.unetmi_layernorm_f_fwd.argtypes = [ci] * 6 + [cf] + [fp] * 4 + [vp]
+    lib.unetmi_tanh_mask_mul.argtypes = [ci] * 5 + [cf] + [fp] * 3 + [vp]
+    lib.unetmi_crf_apply.argtypes = [ci] * 7 + [fp] * 3 + [vp]
+    for f in (lib.unetmi_dwconv2d_fwd, lib.unetmi_layernorm_f_fwd, lib.unetmi_tanh_mask_mul, lib.unetmi_crf_apply):
+        f.restype = ctypes.c_int
     return lib
 
 

@@ -1,0 +1,178 @@
+// Bandwidth-bound kernels around the convolutions: depthwise (grouped) 3x3 dilated
+// convolution of the residual blocks, LayerNorm over the frequency axis, and the
+// mask / ratio-filter application over the (complex) STFT.  Lanes run along time
+// (the contiguous axis), every wave access is one contiguous run, no LDS.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/unetmi.h"
+
+namespace unetmi {
+
+// out[n,c,h,w] = b[c] + sum_{kh,kw} (in [+ in2])[n,c,h-ph+kh*dh, w-pw+kw*dw] * wt[c,kh,kw]   (stride 1, groups = C)
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ in, const float* __restrict__ in2,
+                                                     const float* __restrict__ wt,
+                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                     int C, int H, int W, int ph, int pw, int dh, int dw) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y;
+    const int nc = blockIdx.z;                    // n*C + c
+    if (w >= W) return;
+    const int c = nc % C;
+    const float* src = in + (size_t)nc * H * W;
+    const float* src2 = in2 ? in2 + (size_t)nc * H * W : nullptr;      // optional addend (x + skip)
+    float k[KH * KW];
+#pragma unroll
+    for (int i = 0; i < KH * KW; ++i) k[i] = wt[c * KH * KW + i];   // wave-uniform -> scalar loads
+    float acc = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+        const int ih = h - ph + kh * dh;
+        if ((unsigned)ih >= (unsigned)H) continue;                  // wave-uniform
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+            const int iw = w - pw + kw * dw;
+            float v = 0.f;
+            if ((unsigned)iw < (unsigned)W) {
+                v = src[(size_t)ih * W + iw];
+                if (src2) v += src2[(size_t)ih * W + iw];
+            }
+            acc = fmaf(v, k[kh * KW + kw], acc);
+        }
+    }
+    out[(size_t)nc * H * W + (size_t)h * W + w] = acc;
+}
+
+// LayerNorm over F of x[N,C,F,T] (biased variance), written to channels
+// [c_off, c_off + C) of out[N, C_out, F, T].  One thread per (n, c, t) column: two
+// passes over its F values, each a coalesced row read across the wave.
+__global__ __launch_bounds__(256) void layernorm_f_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ out,
+                                                          int C, int F, int T, int C_out, int c_off, float eps) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int nc = blockIdx.y;
+    if (t >= T) return;
+    const int n = nc / C, c = nc % C;
+    const float* col = x + (size_t)nc * F * T + t;
+    float mean = 0.f;
+    for (int f = 0; f < F; ++f) mean += col[(size_t)f * T];
+    mean /= (float)F;
+    float var = 0.f;
+    for (int f = 0; f < F; ++f) { const float d = col[(size_t)f * T] - mean; var = fmaf(d, d, var); }
+    const float rstd = rsqrtf(var / (float)F + eps);
+    float* dst = out + ((size_t)n * C_out + c_off + c) * F * T + t;
+    for (int f = 0; f < F; ++f) dst[(size_t)f * T] = (col[(size_t)f * T] - mean) * rstd * gamma[f] + beta[f];
+}
+
+// out[n,k,f,t] = (tanh(y[n,k,f,t]) + eps) * x[n,k,f,t], x having Cx >= K channels (first K used)
+__global__ __launch_bounds__(256) void tanh_mask_kernel(const float* __restrict__ y, const float* __restrict__ x,
+                                                        float* __restrict__ out, int K, int Cx, size_t HW,
+                                                        size_t total, float eps) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t sp = i % HW, nk = i / HW;
+    const size_t n = nk / K, k = nk % K;
+    out[i] = (tanhf(y[i]) + eps) * x[(n * Cx + k) * HW + sp];
+}
+
+// Complex ratio filter: Y[b,n,c,f,t] = sum_{p,q} Hf[b,n,c,p,q,f,t] * X[b,c,f+p-Lf,t+q-Lt]  (zero outside).
+// All tensors complex64 viewed as float2; one thread per output element, t innermost.
+__global__ __launch_bounds__(256) void crf_apply_kernel(const float2* __restrict__ Hf, const float2* __restrict__ X,
+                                                        float2* __restrict__ Y, int N, int C, int PF, int PT,
+                                                        int F, int T, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int t = (int)(i % T);
+    const int f = (int)((i / T) % F);
+    const size_t bnc = i / ((size_t)F * T);          // (b*N + n)*C + c
+    const int c = (int)(bnc % C);
+    const size_t b = bnc / ((size_t)N * C);
+    const int Lf = (PF - 1) / 2, Lt = (PT - 1) / 2;
+    const size_t FT = (size_t)F * T;
+    const float2* xs = X + (b * C + c) * FT;
+    float re = 0.f, im = 0.f;
+    for (int p = 0; p < PF; ++p) {
+        const int ff = f + p - Lf;
+        if ((unsigned)ff >= (unsigned)F) continue;
+        for (int q = 0; q < PT; ++q) {
+            const int tt = t + q - Lt;
+            if ((unsigned)tt >= (unsigned)T) continue;
+            const float2 h = Hf[((bnc * PF + p) * PT + q) * FT + (size_t)f * T + t];
+            const float2 v = xs[(size_t)ff * T + tt];
+            re += h.x * v.x - h.y * v.y;
+            im += h.x * v.y + h.y * v.x;
+        }
+    }
+    Y[i] = make_float2(re, im);
+}
+
+}  // namespace unetmi
+
+using namespace unetmi;
+
+namespace unetmi { int api_fail(int code, const std::string& msg); }
+
+extern "C" {
+
+int unetmi_dwconv2d_fwd(int N, int C, int H, int W, int kh, int kw, int ph, int pw, int dh, int dw,
+                        const float* in, const float* in2, const float* weight, const float* bias, float* out,
+                        void* stream) {
+    if (N < 0 || C < 1 || H < 1 || W < 1) return api_fail(UNETMI_E_BAD_DESC, "dwconv: bad sizes");
+    if (2 * ph != dh * (kh - 1) || 2 * pw != dw * (kw - 1))
+        return api_fail(UNETMI_E_UNSUPPORTED, "dwconv: only 'same' padding (2p = d(k-1)) is built");
+    if (N == 0) return UNETMI_OK;
+    if (!in || !weight || !out) return api_fail(UNETMI_E_BAD_ARG, "dwconv: null tensor pointer");
+    if ((long long)N * C > 65535ll * 1024) return api_fail(UNETMI_E_UNSUPPORTED, "dwconv: N*C too large");
+    const dim3 grid((W + 255) / 256, H, N * C), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (kh == 3 && kw == 3) hipLaunchKernelGGL((dwconv_kernel<3, 3>), grid, block, 0, s, in, in2, weight, bias, out, C, H, W, ph, pw, dh, dw);
+    else if (kh == 1 && kw == 3) hipLaunchKernelGGL((dwconv_kernel<1, 3>), grid, block, 0, s, in, in2, weight, bias, out, C, H, W, ph, pw, dh, dw);
+    else if (kh == 3 && kw == 1) hipLaunchKernelGGL((dwconv_kernel<3, 1>), grid, block, 0, s, in, in2, weight, bias, out, C, H, W, ph, pw, dh, dw);
+    else return api_fail(UNETMI_E_UNSUPPORTED, "dwconv: kernel size not built (3x3, 1x3, 3x1)");
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("dwconv launch: ") + hipGetErrorString(e));
+}
+
+int unetmi_layernorm_f_fwd(int N, int C, int F, int T, int C_out, int c_off, float eps, const float* x,
+                           const float* gamma, const float* beta, float* out, void* stream) {
+    if (N < 0 || C < 1 || F < 1 || T < 1 || c_off < 0 || c_off + C > C_out)
+        return api_fail(UNETMI_E_BAD_DESC, "layernorm: bad sizes");
+    if (N == 0) return UNETMI_OK;
+    if (!x || !gamma || !beta || !out) return api_fail(UNETMI_E_BAD_ARG, "layernorm: null tensor pointer");
+    if ((long long)N * C > 65535) return api_fail(UNETMI_E_UNSUPPORTED, "layernorm: N*C > 65535");
+    hipLaunchKernelGGL(layernorm_f_kernel, dim3((T + 255) / 256, N * C), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, gamma, beta, out, C, F, T, C_out, c_off, eps);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("layernorm launch: ") + hipGetErrorString(e));
+}
+
+int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const float* y, const float* x, float* out,
+                         void* stream) {
+    if (N < 0 || K < 1 || Cx < K || F < 1 || T < 1) return api_fail(UNETMI_E_BAD_DESC, "tanh_mask: bad sizes");
+    if (N == 0) return UNETMI_OK;
+    if (!y || !x || !out) return api_fail(UNETMI_E_BAD_ARG, "tanh_mask: null tensor pointer");
+    const size_t total = (size_t)N * K * F * T;
+    hipLaunchKernelGGL(tanh_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       y, x, out, K, Cx, (size_t)F * T, total, eps);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("tanh_mask launch: ") + hipGetErrorString(e));
+}
+
+int unetmi_crf_apply(int B, int N, int C, int PF, int PT, int F, int T, const float* Hf, const float* X, float* Y,
+                     void* stream) {
+    if (B < 0 || N < 1 || C < 1 || PF < 1 || PT < 1 || !(PF & 1) || !(PT & 1) || F < 1 || T < 1)
+        return api_fail(UNETMI_E_BAD_DESC, "crf_apply: bad sizes (tap counts must be odd)");
+    if (B == 0) return UNETMI_OK;
+    if (!Hf || !X || !Y) return api_fail(UNETMI_E_BAD_ARG, "crf_apply: null tensor pointer");
+    const size_t total = (size_t)B * N * C * F * T;
+    if ((total + 255) / 256 > 0x7fffffffull) return api_fail(UNETMI_E_UNSUPPORTED, "crf_apply: too many elements");
+    hipLaunchKernelGGL(crf_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float2*>(Hf), reinterpret_cast<const float2*>(X),
+                       reinterpret_cast<float2*>(Y), N, C, PF, PT, F, T, total);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("crf_apply launch: ") + hipGetErrorString(e));
+}
+
+}  // extern "C"

@@ -26,6 +26,7 @@ static int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+int api_fail(int code, const std::string& msg) { return fail(code, msg); }   // for the other translation units
 }  // namespace unetmi
 
 using namespace unetmi;

@@ -59,8 +59,13 @@ def require_device_tensor(x, who):
 class FusedConv:
     """conv [+ BatchNorm2d(eval)] [+ activation] as ONE kernel launch."""
 
-    def __init__(self, conv, norm=None, act=None, act_first=False):
+    def __init__(self, conv, norm=None, act=None, act_first=False, swap_hw=False):
+        """swap_hw: the conv module is defined on [B,C,T,F] (time and frequency
+        exchanged, as ResUNet's input layers are, ResUNet.py:165-170) but is applied
+        to the unpermuted [B,C,F,T] tensor: kernel, padding, stride and dilation
+        swap their two axes and so does the weight."""
         self.conv, self.norm, self.act, self.act_first = conv, norm, act, bool(act_first)
+        self.swap_hw = bool(swap_hw)
         self._key = None
         self._state = None
 
@@ -85,6 +90,8 @@ class FusedConv:
         ph, pw = _pair(c.padding)
         dh, dw = _pair(c.dilation)
         oph, opw = _pair(c.output_padding) if transposed else (0, 0)
+        if self.swap_hw:
+            kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = kw, kh, sw, sh, pw, ph, dw, dh, opw, oph
         return [c.out_channels, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw], int(transposed)
 
     # -- cache ---------------------------------------------------------------------
@@ -114,7 +121,8 @@ class FusedConv:
         found = activation_code(self.act)
         code, par = found if found is not None else (_lib.ACT_NONE, None)
         with torch.no_grad():
-            wpacked = pack_conv_weights(c.weight, c.in_channels, 0, geom,
+            weight = c.weight.permute(0, 1, 3, 2) if self.swap_hw else c.weight
+            wpacked = pack_conv_weights(weight, c.in_channels, 0, geom,
                                         [transposed, _lib.IN_SINGLE, code, 0]).to(device)
             f32 = dict(dtype=torch.float32, device=device)
             bias = (c.bias.detach().to(**f32) if c.bias is not None else torch.zeros(K, **f32)).contiguous()

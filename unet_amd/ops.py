@@ -139,3 +139,103 @@ def _conv2d_fwd_fake(in0, in1, wpacked, bias, scale, shift, act_param, gate, res
 
 
 conv2d_fwd = torch.ops.unetmi.conv2d_fwd
+
+
+# ---------------------------------------------------------------------------------------
+# bandwidth-bound ops (csrc/pointwise.hip)
+# ---------------------------------------------------------------------------------------
+_LIBRARY.define("dwconv2d_fwd(Tensor x, Tensor? x2, Tensor weight, Tensor? bias, int[] padding, int[] dilation) -> Tensor")
+_LIBRARY.define("layernorm_f(Tensor x, Tensor gamma, Tensor beta, float eps, Tensor(a!) out, int c_off) -> ()")
+_LIBRARY.define("tanh_mask_mul(Tensor y, Tensor x, float eps) -> Tensor")
+_LIBRARY.define("crf_apply(Tensor H, Tensor X) -> Tensor")
+
+
+def _dev(t, name, op):
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError("unetmi::{}: {} must be a contiguous fp32 device tensor".format(op, name))
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dwconv2d_fwd_cuda(x, x2, weight, bias, padding, dilation):
+    _dev(x, "x", "dwconv2d_fwd"), _dev(weight, "weight", "dwconv2d_fwd")
+    N, C, H, W = x.shape
+    if tuple(weight.shape[:2]) != (C, 1):
+        raise ValueError("unetmi::dwconv2d_fwd: weight must be [C,1,kh,kw]")
+    if x2 is not None:
+        _dev(x2, "x2", "dwconv2d_fwd")
+        if x2.shape != x.shape:
+            raise ValueError("unetmi::dwconv2d_fwd: x2 shape differs from x")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(_lib.lib.unetmi_dwconv2d_fwd(N, C, H, W, weight.shape[2], weight.shape[3], padding[0], padding[1],
+                                           dilation[0], dilation[1], _ptr(x), _ptr(x2), _ptr(weight), _ptr(bias),
+                                           _ptr(out), _stream(x)), "unetmi_dwconv2d_fwd")
+    return out
+
+
+def _layernorm_f_cuda(x, gamma, beta, eps, out, c_off):
+    _dev(x, "x", "layernorm_f"), _dev(out, "out", "layernorm_f")
+    N, C, F, T = x.shape
+    if out.shape[0] != N or tuple(out.shape[2:]) != (F, T) or gamma.numel() != F or beta.numel() != F:
+        raise ValueError("unetmi::layernorm_f: shape mismatch")
+    with torch.cuda.device(x.device):
+        check(_lib.lib.unetmi_layernorm_f_fwd(N, C, F, T, out.shape[1], c_off, eps, _ptr(x), _ptr(gamma), _ptr(beta),
+                                              _ptr(out), _stream(x)), "unetmi_layernorm_f_fwd")
+
+
+def _tanh_mask_mul_cuda(y, x, eps):
+    _dev(y, "y", "tanh_mask_mul"), _dev(x, "x", "tanh_mask_mul")
+    N, K, F, T = y.shape
+    if x.shape[0] != N or x.shape[1] < K or tuple(x.shape[2:]) != (F, T):
+        raise ValueError("unetmi::tanh_mask_mul: x must be [N, >=K, F, T]")
+    out = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        check(_lib.lib.unetmi_tanh_mask_mul(N, K, x.shape[1], F, T, eps, _ptr(y), _ptr(x), _ptr(out), _stream(y)),
+              "unetmi_tanh_mask_mul")
+    return out
+
+
+def _crf_apply_cuda(H, X):
+    if not (H.is_cuda and X.is_cuda and H.dtype == torch.complex64 and X.dtype == torch.complex64
+            and H.is_contiguous() and X.is_contiguous() and H.dim() == 7 and X.dim() == 4):
+        raise ValueError("unetmi::crf_apply: H [B,N,C,PF,PT,F,T] and X [B,C,F,T] must be contiguous complex64 "
+                         "device tensors")
+    B, N, C, PF, PT, F, T = H.shape
+    if tuple(X.shape) != (B, C, F, T):
+        raise ValueError("unetmi::crf_apply: X is {}, expected {}".format(tuple(X.shape), (B, C, F, T)))
+    Y = torch.empty((B, N, C, F, T), dtype=torch.complex64, device=H.device)
+    with torch.cuda.device(H.device):
+        check(_lib.lib.unetmi_crf_apply(B, N, C, PF, PT, F, T, torch.view_as_real(H).data_ptr(),
+                                        torch.view_as_real(X).data_ptr(), torch.view_as_real(Y).data_ptr(),
+                                        _stream(H)), "unetmi_crf_apply")
+    return Y
+
+
+_LIBRARY.impl("dwconv2d_fwd", _dwconv2d_fwd_cuda, "CUDA")
+_LIBRARY.impl("layernorm_f", _layernorm_f_cuda, "CUDA")
+_LIBRARY.impl("tanh_mask_mul", _tanh_mask_mul_cuda, "CUDA")
+_LIBRARY.impl("crf_apply", _crf_apply_cuda, "CUDA")
+
+
+@torch.library.register_fake("unetmi::dwconv2d_fwd")
+def _(x, x2, weight, bias, padding, dilation):
+    return torch.empty_like(x)
+
+
+@torch.library.register_fake("unetmi::tanh_mask_mul")
+def _(y, x, eps):
+    return torch.empty_like(y)
+
+
+@torch.library.register_fake("unetmi::crf_apply")
+def _(H, X):
+    return H.new_empty((H.shape[0], H.shape[1], H.shape[2], H.shape[5], H.shape[6]))
+
+
+dwconv2d_fwd = torch.ops.unetmi.dwconv2d_fwd
+layernorm_f = torch.ops.unetmi.layernorm_f
+tanh_mask_mul = torch.ops.unetmi.tanh_mask_mul
+crf_apply = torch.ops.unetmi.crf_apply
