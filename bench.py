@@ -14,8 +14,7 @@ cross-sample op); a barrier brackets the timed region and the maximum time
 over ranks is used.
 
 Rank 0 prints ONE JSON line.  "roofline" is for the dominant kernel
-(conv_dma_kernel<1,4,2,2,...>: every plain conv and the transposed convs
-with time stride 1; its per-kernel-width instantiations are summed), from HIP events recorded on the launch stream around each of its
+(the conv_dma_kernel instantiation with the largest share of the step), from HIP events recorded on the launch stream around each of its
 launches inside the timed region: algorithmic FLOPs (2 x MACs of the layer)
 / launch time, against the dense fp32 MFMA peak.  "cpu_baseline" times the
 CPU oracle (this repository's restatement of the reference, stock torch CPU
@@ -55,16 +54,36 @@ def conv_macs(d):
 
 
 def kernel_variant(d):
-    """Which conv_mfma_kernel instantiation serves this layer."""
+    """Name of the kernel instantiation that serves this layer, as rocprofv3 prints it
+    (mirrors the dispatch in unet_amd/csrc/conv_mfma.hip and conv_plan.hpp)."""
     cin = d.C0 + (d.C1 if d.in_mode == 1 else 0)
     if (d.kw == 1 and d.sw == 1 and d.sh == 1 and d.dh == 1 and d.kh in (1, 3, 7)
             and (d.K <= 2 or (d.K <= 32 and cin * d.kh <= 112))):
-        return "direct_conv_kernel"
+        rpt, kt = (8, d.K) if d.K <= 2 else (2, 16)
+        return "direct_conv_kernel<{}, {}, {}>".format(rpt, kt, d.kh)
     ng = d.sw if d.transposed else 1
     wn = 1 if d.K <= 32 else 2
     if d.in_mode == 2:
-        return "conv_mfma_kernel<{},4,{},{},true>".format(ng, 4 // wn, wn)
-    return "conv_dma_kernel<{},4,{},{}>".format(ng, 4 // wn, wn)
+        return "conv_mfma_kernel<{}, 4, {}, {}, true, 0, 0>".format(ng, 4 // wn, wn)
+    ntw = (0, 0)
+    if d.dw == 1 or (d.transposed and d.sw == 2):
+        if ng == 1 and d.kw in (1, 3, 5, 7):
+            ntw = (d.kw, 0)
+        elif ng == 2:
+            taps = tuple(len([k for k in range(d.kw) if k % 2 == (b + d.pw) % 2]) for b in (0, 1))
+            if taps in ((1, 2), (3, 2)):
+                ntw = taps
+    return "conv_dma_kernel<{}, 4, {}, {}, {}, {}>".format(ng, 4 // wn, wn, ntw[0], ntw[1])
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/summarise_profiles.py), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
 def cpu_baseline(threads):
@@ -178,7 +197,7 @@ def main():
                        "gflop_per_utterance": 64.34, "parallelism": "batch-sharded x{}".format(world)},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(dominant),
                          "launches": launches, "avg_launch_ms": 1e3 * secs / launches,
                          "gflop_per_launch": flops / launches / 1e9,
                          "all_kernels": {k: {"tflops": v[0] / v[1] / 1e12, "ms": 1e3 * v[1] / args.steps,
