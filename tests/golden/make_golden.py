@@ -158,6 +158,28 @@ def main():
             arrays["post/" + k] = v.reshape(-1)[sample_index(v.numel(), 8)].numpy()
         save("unet_narrow_trainstep", **arrays)
 
+    # ---------------------------------------------------------------- UNet, benchmark size
+    print("UNet (table T1, f_dim=32, c_in=2, c_last=1), B=1 F=257 T=509: per-layer checksums")
+    enc_rows, dec_rows = unet20_layers(c_in=2, c_last=1, f_dim=32)
+    ref = R_UNet.UNet([R_m.Encoder(*r["args"], **r["kw"]) for r in enc_rows],
+                      [R_m.Decoder(*r["args"], **r["kw"]) for r in dec_rows])
+    seeded_fill_(ref, seed=13)
+    mine = oracle.UNet(*oracle.default_unet(c_in=2, c_last=1, f_dim=32))
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    x = normal("unet_full509/x", (1, 2, 257, 509), seed=13)
+    ref.eval(), mine.eval()
+    store, handles = hook_outputs(ref, layer_names)
+    with torch.no_grad():
+        y_ref, y_mine = ref(x), mine(x)
+    for h in handles:
+        h.remove()
+    require_equal(y_ref, y_mine, "UNet full-size eval")
+    if out is not None:
+        arrays = flat_summary("out", y_ref)
+        for n in layer_names:
+            arrays.update(flat_summary(n, store[n]))
+        save("unet_full_eval_T509", **arrays)
+
     # ---------------------------------------------------------------- UNet20
     for T in (29, 125):
         print("cRFUNet.UNet20 as shipped (f_dim=32, c_in=14), B=1 F=257 T={}".format(T))

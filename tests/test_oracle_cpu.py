@@ -38,6 +38,19 @@ def test_unet_narrow_matches_golden():
     np.testing.assert_allclose(got, g["layer_sum"], rtol=1e-4, atol=1e-3)
 
 
+def test_unet_benchmark_size_matches_golden():
+    """Full channel widths at T=509 (one utterance): output summary recorded from the reference."""
+    m = oracle.UNet(*oracle.default_unet(c_in=2, c_last=1, f_dim=32)).eval()
+    seeded_fill_(m, seed=13)
+    x = normal("unet_full509/x", (1, 2, 257, 509), seed=13)
+    with torch.no_grad():
+        y = m(x).reshape(-1).double().numpy()
+    g = load_golden("unet_full_eval_T509")
+    assert y.size == int(g["out_numel"])
+    assert np.abs(y[sample_index(y.size)] - g["out_samples"]).max() <= CPU_TOL * np.abs(g["out_samples"]).max()
+    assert abs(y.sum() - float(g["out_sum"])) <= CPU_TOL * y.size
+
+
 @pytest.mark.parametrize("T", [29, 125])
 def test_unet20_matches_golden(T):
     net = oracle.UNet20().eval()

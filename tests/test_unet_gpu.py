@@ -56,3 +56,40 @@ def test_batch_independence(device):
         whole = dev(x)
         parts = torch.cat([dev(x[i:i + 1]) for i in range(3)])
     assert torch.equal(whole, parts)
+
+
+LAYER_NAMES = ["encoder_{}".format(i) for i in range(10)] + ["decoder_{}".format(i) for i in range(10)]
+
+
+def test_benchmark_size_batch_against_golden_and_oracle(device):
+    """The benchmark workload itself: batch 64 x [2,257,509], full channel widths.
+    Sample 0 is the golden input, so every layer's output for it is checked against the
+    reference's per-layer checksums and samples; two other samples are checked against the
+    oracle run on them alone (the batch is independent per sample)."""
+    from unet_amd.seeding import normal
+    from tests.util import sample_index
+    ref, dev = _pair(32, 2, 1, seed=13)
+    dev.to(device)
+    x = normal("unet_full509/batch", (64, 2, 257, 509), seed=14)
+    x[0] = normal("unet_full509/x", (1, 2, 257, 509), seed=13)[0]
+    store = {}
+    mods = dict(dev.named_modules())
+    handles = [mods[n].register_forward_hook(lambda m, i, o, n=n: store.__setitem__(n, o[0].detach().cpu()))
+               for n in LAYER_NAMES]
+    with torch.no_grad():
+        got = dev(x.to(device)).cpu()
+    for h in handles:
+        h.remove()
+    golden = load_golden("unet_full_eval_T509")
+    for n in LAYER_NAMES + ["out"]:
+        t = (got[0] if n == "out" else store[n]).reshape(-1).double().numpy()
+        assert t.size == int(golden[n + "_numel"]), n
+        want = golden[n + "_samples"].astype(np.float64)
+        have = t[sample_index(t.size)]
+        scale = np.sqrt(float(golden[n + "_sumsq"]) / t.size)          # rms of the layer output
+        assert np.abs(have - want).max() <= 1e-4 * max(np.abs(want).max(), scale), n
+        assert abs((t * t).sum() - float(golden[n + "_sumsq"])) <= 1e-4 * float(golden[n + "_sumsq"]), n
+        assert abs(t.sum() - float(golden[n + "_sum"])) <= 1e-4 * scale * t.size, n
+    with torch.no_grad():
+        for i in (31, 63):
+            assert_close(got[i:i + 1], ref(x[i:i + 1]), what="sample {} of the batch".format(i))
