@@ -164,6 +164,65 @@ int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const fl
 int unetmi_crf_apply(int B, int N, int C, int PF, int PT, int F, int T, const float* Hf, const float* X, float* Y,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training step (train()-mode forward and backward of Encoder / Decoder, UNet_m.py:340-345,
+ * :379-383, under torch autograd in the reference).  Train-mode forward of a block is
+ *   z = unetmi_conv2d_fwd(act NONE, scale/shift null)          conv / transconv (+ bias)
+ *   unetmi_bn_train_stats(z)  -> batch mean, 1/sqrt(var+eps), running-stat update
+ *   y = unetmi_bn_act_fwd(z)                                   bn -> acti
+ * and its backward
+ *   dz, dgamma, dbeta, dbias = unetmi_bn_act_bwd(dy, z)
+ *   dW = unetmi_conv2d_wgrad(input, dz)
+ *   dx = unetmi_conv2d_fwd with the transposed flag flipped (a conv's input gradient is the
+ *        transposed conv of dz with the same weight tensor, and vice versa).
+ * Workspaces are caller-allocated device memory; their contents are scratch.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Bytes of workspace unetmi_bn_train_stats / unetmi_bn_act_bwd need for z[N,C,HW]. */
+size_t unetmi_bn_workspace_bytes(int N, int C, int HW);
+
+/* Batch statistics of z[N,C,HW] over (N,HW) per channel (nn.BatchNorm2d in train mode, UNet_m.py:322):
+ * mean[c], invstd[c] = 1/sqrt(biased_var + eps); when non-null, running_mean / running_var are
+ * updated in place as r = (1-momentum) r + momentum * stat with the UNBIASED variance. */
+int unetmi_bn_train_stats(int N, int C, int HW, const float* z, float eps, float momentum, float* running_mean,
+                          float* running_var, float* mean, float* invstd, void* ws, size_t ws_bytes, void* stream);
+
+/* out = act((z - mean) * invstd * gamma + beta), act = UNETMI_ACT_* with one shared parameter
+ * (act_param[0], LeakyReLU slope) or none. */
+int unetmi_bn_act_fwd(int N, int C, int HW, const float* z, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int act, const float* act_param, float* out,
+                      void* stream);
+
+/* Backward of unetmi_bn_act_fwd composed with train-mode batch statistics:
+ *   g = dy * act'(u),  dbeta = sum g,  dgamma = sum g * xhat,
+ *   dz = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)),  dbias = sum dz  (the conv bias gradient).
+ * dy is [N,C,HW] with element (n,c,i) at dy[n * dy_batch_stride + c * HW + i], so a channel slice
+ * of a wider gradient tensor can be passed without a copy (dy_batch_stride = C*HW when dense).
+ * With batch_stats = 0 mean/invstd are constants (eval-mode BatchNorm, or mean 0 / invstd 1 / gamma 1 /
+ * beta 0 for a layer without a norm): dz = gamma * invstd * g, the two mean terms drop out.
+ * dgamma / dbeta / dbias may be null. */
+int unetmi_bn_act_bwd(int N, int C, int HW, const float* dy, long long dy_batch_stride, const float* z,
+                      const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                      const float* act_param, int batch_stats, float* dz, float* dgamma, float* dbeta,
+                      float* dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* Weight gradient of the layer d describes (same descriptor as the forward; epilogue fields ignored).
+ *   transposed = 0:  dweight[K][C0][kh][kw]      = correlate(dout[N,K,OH,OW], in0[N,C0,H,W])
+ *   transposed = 1:  dweight[C0+C1][K][kh][kw]   = correlate(cat(in0,in1)[N,C0+C1,H,W], dout[N,K,OH,OW])
+ * i.e. what autograd computes for nn.Conv2d.weight / nn.ConvTranspose2d.weight (UNet_m.py:321, :361).
+ * Deterministic (fixed summation order).  ws: unetmi_conv2d_wgrad_workspace_bytes(d) bytes. */
+size_t unetmi_conv2d_wgrad_workspace_bytes(const UnetmiConvDesc* d);
+int unetmi_conv2d_wgrad(const UnetmiConvDesc* d, const float* in0, const float* in1, const float* dout,
+                        float* dweight, void* ws, size_t ws_bytes, void* stream);
+
+/* One Adam update (torch.optim.Adam defaults: no amsgrad; weight_decay is L2 added to the gradient) over
+ * a flat bucket of n parameters: g = grad * grad_scale (+ weight_decay * p); m, v updated in place;
+ * p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps).  step counts from 1.
+ * grad_scale = 1 / world_size turns a summed all-reduce into the data-parallel mean. */
+int unetmi_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

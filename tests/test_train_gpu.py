@@ -1,0 +1,201 @@
+"""Training-step kernels against torch CPU autograd (the arithmetic the reference trains with) and
+against the golden training step recorded from the reference."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from tests.util import assert_close, load_golden, sample_index
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("act", ["leaky", "relu", "silu", "none"])
+def test_bn_train_forward_backward(device, act):
+    from unet_amd import _lib
+    from unet_amd.train import bn_act_bwd, bn_act_fwd, bn_train_stats
+    code = dict(leaky=_lib.ACT_LEAKY, relu=_lib.ACT_RELU, silu=_lib.ACT_SILU, none=_lib.ACT_NONE)[act]
+    fn = dict(leaky=lambda t: F.leaky_relu(t, 0.01), relu=F.relu, silu=F.silu, none=lambda t: t)[act]
+    N, C, H, W = 3, 5, 17, 29
+    z = (_rand((N, C, H, W), 1) * 2 + 0.7).requires_grad_()
+    bn = nn.BatchNorm2d(C).train()
+    with torch.no_grad():
+        bn.weight.copy_(_rand((C,), 2).abs() + 0.5)
+        bn.bias.copy_(_rand((C,), 3))
+    dy_wide = _rand((N, C + 3, H, W), 4)
+    dy = dy_wide[:, 2:2 + C]
+    y = fn(bn(z))
+    y.backward(dy)
+    rm, rv = torch.zeros(C, device=device), torch.ones(C, device=device)
+    zd = z.detach().to(device)
+    mean, invstd = bn_train_stats(zd, bn.eps, bn.momentum, rm, rv)
+    par = torch.full((1,), 0.01, device=device) if act == "leaky" else None
+    gam, bet = bn.weight.detach().to(device), bn.bias.detach().to(device)
+    yd = bn_act_fwd(zd, mean, invstd, gam, bet, code, par)
+    assert_close(yd, y, tol=1e-5, what="bn+act forward")
+    assert_close(rm, bn.running_mean, tol=1e-5, what="running_mean")
+    assert_close(rv, bn.running_var, tol=1e-5, what="running_var")
+    dz, dgamma, dbeta, dbias = bn_act_bwd(dy_wide.to(device)[:, 2:2 + C], zd, mean, invstd, gam, bet, code, par, True)
+    assert_close(dz, z.grad, tol=1e-4, what="dz")
+    assert_close(dgamma, bn.weight.grad, tol=1e-5, what="dgamma")
+    assert_close(dbeta, bn.bias.grad, tol=1e-5, what="dbeta")
+    assert dbias.abs().max().item() <= 1e-4 * dy.abs().sum().item() / C      # sums to zero up to rounding
+
+
+WGRAD_CASES = [
+    # transposed, C0, C1, K, H, W, k, s, p, op
+    (0, 6, 0, 10, 13, 37, (7, 5), (2, 2), (3, 2), (0, 0)),
+    (0, 64, 0, 64, 9, 40, (7, 5), (2, 1), (3, 2), (0, 0)),
+    (0, 32, 0, 64, 5, 70, (1, 7), (1, 1), (0, 3), (0, 0)),
+    (0, 2, 0, 32, 20, 33, (7, 1), (1, 1), (3, 0), (0, 0)),
+    (0, 64, 0, 64, 11, 33, (5, 3), (2, 2), (2, 1), (0, 0)),
+    (0, 1, 0, 1, 9, 45, (1, 1), (1, 1), (0, 0), (0, 0)),
+    (1, 64, 64, 64, 5, 19, (7, 5), (2, 2), (3, 2), (0, 0)),
+    (1, 64, 64, 64, 4, 32, (5, 3), (2, 2), (2, 1), (0, 1)),
+    (1, 20, 13, 7, 6, 35, (5, 3), (2, 1), (2, 1), (0, 0)),
+    (1, 64, 32, 1, 12, 33, (7, 1), (1, 1), (3, 0), (0, 0)),
+    (1, 64, 64, 64, 6, 70, (1, 7), (1, 1), (0, 3), (0, 0)),
+    (1, 64, 0, 64, 2, 32, (5, 3), (2, 1), (2, 1), (0, 0)),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "{}{}+{}-{}k{}x{}s{}x{}".format(
+    "T" if c[0] else "C", c[1], c[2], c[3], c[6][0], c[6][1], c[7][0], c[7][1]))
+def test_wgrad_and_input_gradient(device, case):
+    from unet_amd import _lib
+    from unet_amd.ops import make_desc
+    from unet_amd.train import _input_gradient, conv2d_wgrad
+    transposed, C0, C1, K, H, W, k, s, p, op = case
+    N = 3
+    cin = C0 + C1
+    x = _rand((N, cin, H, W), 11).requires_grad_()
+    if transposed:
+        conv = nn.ConvTranspose2d(cin, K, k, s, p, output_padding=op)
+    else:
+        conv = nn.Conv2d(cin, K, k, s, p)
+    y = conv(x)
+    dy = _rand(tuple(y.shape), 12)
+    y.backward(dy)
+    geom = [K, k[0], k[1], s[0], s[1], p[0], p[1], 1, 1, op[0], op[1]]
+    d = make_desc(N, C0, C1, H, W, geom, [transposed, _lib.IN_CONCAT if C1 else _lib.IN_SINGLE, 0, 0])
+    xd = x.detach().to(device)
+    in0 = xd[:, :C0].contiguous()
+    in1 = xd[:, C0:].contiguous() if C1 else None
+    dyd = dy.to(device)
+    dw = conv2d_wgrad(d, in0, in1, dyd)
+    assert_close(dw, conv.weight.grad, tol=2e-5, what="weight gradient")
+    dw2 = conv2d_wgrad(d, in0, in1, dyd)
+    assert torch.equal(dw, dw2), "weight gradient is not reproducible"
+    dx = _input_gradient(dyd, conv.weight.detach().to(device), geom, bool(transposed), (H, W))
+    assert_close(dx, x.grad, tol=2e-5, what="input gradient")
+
+
+def test_adam_matches_torch(device):
+    from unet_amd.train import adam_step
+    n = 100003
+    p0, g = _rand((n,), 21), _rand((n,), 22) * 1e-2
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.to(device)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in (1, 2, 3):
+        ref.grad = g * step
+        opt.step()
+        adam_step(p, (g * step).to(device), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, step)
+        assert_close(p - p0.to(device), ref.detach() - p0, tol=1e-5, what="update after step {}".format(step))
+
+
+def _narrow_pair(seed):
+    import oracle
+    import unet_amd
+    ref = oracle.UNet(*oracle.default_unet(c_in=2, c_last=1, f_dim=8))
+    unet_amd.seeded_fill_(ref, seed=seed)
+    dev = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=8))
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    return ref, dev
+
+
+def test_train_step_matches_golden_and_oracle(device):
+    """Loss, every gradient, BatchNorm running statistics and parameters after one Adam step of the
+    narrow UNet: device vs the oracle run here, and vs the values recorded from the reference."""
+    from unet_amd.seeding import normal, uniform
+    from unet_amd.train import FlatAdam
+    ref, dev = _narrow_pair(11)
+    xb = normal("unet_narrow/xb", (2, 2, 257, 29), seed=12)
+    target = uniform("unet_narrow/target", (2, 1, 257, 29), 0.0, 1.0, seed=12)
+    ref.train()
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    opt_ref.zero_grad()
+    loss_ref = torch.mean((ref(xb) - target) ** 2)
+    loss_ref.backward()
+    grads_ref = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    before = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    opt_ref.step()
+
+    dev.to(device).train()
+    opt = FlatAdam(dev.parameters(), lr=1e-3)
+    opt.zero_grad()
+    loss = torch.mean((dev(xb.to(device)) - target.to(device)) ** 2)
+    loss.backward()
+    golden = load_golden("unet_narrow_trainstep")
+    assert abs(loss.item() - float(golden["loss"])) <= 1e-5 * abs(float(golden["loss"]))
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    # gradients: tolerance relative to the largest gradient of the same KIND of tensor, so the conv
+    # biases (whose true gradient under train-mode BatchNorm is zero) are held to rounding level
+    gmax = max(g.abs().max().item() for g in grads_ref.values())
+    for k, p in dev.named_parameters():
+        g, want = p.grad.detach().cpu(), grads_ref[k]
+        scale = max(want.abs().max().item(), 1e-3 * gmax)
+        err = (g - want).abs().max().item()
+        assert err <= 1e-4 * scale, "grad {}: err {:.3e} vs scale {:.3e}".format(k, err, scale)
+        gs = golden["grad/" + k]
+        have = g.reshape(-1)[torch.from_numpy(sample_index(g.numel(), 8))].numpy()
+        assert np.abs(have - gs).max() <= 1e-4 * scale, "golden grad " + k
+    opt.step()
+    after_ref = ref.state_dict()
+    for k, v in dev.state_dict().items():
+        want = after_ref[k].float()
+        if k.endswith("num_batches_tracked"):
+            assert int(v.item()) == int(want.item())
+            continue
+        delta_ref = want - before[k].float()
+        delta = v.detach().cpu().float() - before[k].float()
+        tol = 1e-3 * max(delta_ref.abs().max().item(), 1e-12) + 1e-6 * want.abs().max().item()
+        assert (delta - delta_ref).abs().max().item() <= tol, "post-step " + k
+        gs = golden["post/" + k]
+        have = v.detach().cpu().float().reshape(-1)[torch.from_numpy(sample_index(v.numel(), 8))].numpy()
+        assert np.abs(have - gs).max() <= 1e-4 * max(np.abs(gs).max(), 1e-6) + 2e-6, "golden post-step " + k
+
+
+def test_eval_after_training_uses_updated_weights(device):
+    """The inference kernels cache packed weights; an optimizer step must invalidate them."""
+    from unet_amd.seeding import normal, uniform
+    from unet_amd.train import FlatAdam, train_step
+    ref, dev = _narrow_pair(7)
+    dev.to(device)
+    x = normal("t/x", (2, 2, 257, 29), seed=1).to(device)
+    target = uniform("t/y", (2, 1, 257, 29), 0.0, 1.0, seed=1).to(device)
+    dev.eval()
+    with torch.no_grad():
+        y0 = dev(x)
+    dev.train()
+    opt = FlatAdam(dev.parameters(), lr=1e-2)
+    l0 = train_step(dev, opt, x, target)
+    l1 = train_step(dev, opt, x, target)
+    assert l1.item() < l0.item()
+    dev.eval()
+    with torch.no_grad():
+        y1 = dev(x)
+    ref.load_state_dict({k: v.cpu() for k, v in dev.state_dict().items()}, strict=True)
+    ref.eval()
+    with torch.no_grad():
+        want = ref(x.cpu())
+    assert not torch.equal(y0, y1)
+    assert_close(y1, want, what="eval forward after two optimizer steps")

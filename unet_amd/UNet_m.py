@@ -62,9 +62,7 @@ class _FusedBlock(nn.Module):
     def _run(self, x, skip=None, in_mode=None, gate=None):
         require_device_tensor(x, type(self).__name__)
         if self.training:
-            raise NotImplementedError(
-                "{}: train-mode forward (batch statistics) is not available in this build; "
-                "call .eval()".format(type(self).__name__))
+            return self._run_differentiable(x, skip, in_mode, gate)
         layer = self._layer()
         if layer.fusable():
             return layer(x, skip, in_mode=in_mode, gate=gate)
@@ -73,6 +71,26 @@ class _FusedBlock(nn.Module):
         if gate is not None:
             y = y * gate[:, :, None, None]
         return y
+
+    def _run_differentiable(self, x, skip, in_mode, gate):
+        """train() mode: batch statistics, and forward and backward are HIP launches recorded as
+        one autograd node (unet_amd/train.py).  eval() mode is inference only: its output carries
+        no autograd history."""
+        from .fused import activation_code
+        from .train import conv_norm_act
+        who = type(self).__name__
+        found = activation_code(self.acti)
+        if found is None or isinstance(found[1], torch.Tensor):
+            raise NotImplementedError("{}: differentiable forward is not built for {}".format(
+                who, type(self.acti).__name__))
+        if gate is not None or (in_mode is not None and in_mode != _lib.IN_CONCAT):
+            raise NotImplementedError("{}: differentiable forward with a gate or a summed skip is not built".format(who))
+        drop = getattr(self, "dropout", None)
+        if drop is not None and drop.p != 0.0 and self.training:
+            raise NotImplementedError("{}: dropout with p > 0 is not built".format(who))
+        code, par = found
+        act_param = None if par is None else torch.full((1,), par, dtype=torch.float32, device=x.device)
+        return conv_norm_act(getattr(self, self._conv_attr), self.bn, code, act_param, x, skip)
 
 
 class Encoder(_FusedBlock):

@@ -25,6 +25,13 @@ EXPORTED_SYMBOLS = (
     "unetmi_layernorm_f_fwd",
     "unetmi_tanh_mask_mul",
     "unetmi_crf_apply",
+    "unetmi_bn_workspace_bytes",
+    "unetmi_bn_train_stats",
+    "unetmi_bn_act_fwd",
+    "unetmi_bn_act_bwd",
+    "unetmi_conv2d_wgrad_workspace_bytes",
+    "unetmi_conv2d_wgrad",
+    "unetmi_adam_step",
 )
 
 
@@ -69,6 +76,19 @@ def _load():
     lib.unetmi_layernorm_f_fwd.argtypes = [ci] * 6 + [cf] + [fp] * 4 + [vp]
     lib.unetmi_tanh_mask_mul.argtypes = [ci] * 5 + [cf] + [fp] * 3 + [vp]
     lib.unetmi_crf_apply.argtypes = [ci] * 7 + [fp] * 3 + [vp]
+    sz, ll = ctypes.c_size_t, ctypes.c_longlong
+    lib.unetmi_bn_workspace_bytes.argtypes = [ci] * 3
+    lib.unetmi_bn_workspace_bytes.restype = sz
+    lib.unetmi_bn_train_stats.argtypes = [ci] * 3 + [fp, cf, cf] + [fp] * 4 + [vp, sz, vp]
+    lib.unetmi_bn_act_fwd.argtypes = [ci] * 3 + [fp] * 5 + [ci, fp, fp, vp]
+    lib.unetmi_bn_act_bwd.argtypes = [ci] * 3 + [fp, ll] + [fp] * 5 + [ci, fp, ci] + [fp] * 4 + [vp, sz, vp]
+    lib.unetmi_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+    lib.unetmi_conv2d_wgrad_workspace_bytes.restype = sz
+    lib.unetmi_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 4 + [vp, sz, vp]
+    lib.unetmi_adam_step.argtypes = [sz] + [fp] * 4 + [cf] * 6 + [ci, vp]
+    for f in (lib.unetmi_bn_train_stats, lib.unetmi_bn_act_fwd, lib.unetmi_bn_act_bwd, lib.unetmi_conv2d_wgrad,
+              lib.unetmi_adam_step):
+        f.restype = ctypes.c_int
     for f in (lib.unetmi_dwconv2d_fwd, lib.unetmi_layernorm_f_fwd, lib.unetmi_tanh_mask_mul, lib.unetmi_crf_apply):
         f.restype = ctypes.c_int
     return lib

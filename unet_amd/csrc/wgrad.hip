@@ -1,0 +1,369 @@
+// Weight gradient of Conv2d / ConvTranspose2d on the fp32 matrix cores.
+//
+// Both cases are one correlation
+//     dW[a][b][r][s] = sum_{n,p,q} P[n,a,p,q] * Q[n,b, p*sh - ph + r*dh, q*sw - pw + s*dw]
+// Conv2d:          P = gradient of the conv output [N,K,OH,OW], Q = layer input [N,C,H,W]  -> dW[K][C][kh][kw]
+// ConvTranspose2d: P = layer input [N,Cin,H,W] (optionally two tensors concatenated along channels),
+//                  Q = gradient of the output [N,Cout,OH,OW]                                 -> dW[Cin][Cout][kh][kw]
+// which are torch's weight layouts, so one kernel serves both.
+//
+// The reduction runs over pixels, so it maps to v_mfma_f32_16x16x4_f32 with k = 4 consecutive
+// pixels of one row: A operand = P[a = lane&15][pixel lane>>4], B operand = Q[b = lane&15][shifted
+// pixel lane>>4], D = a 16x16 block of dW for one tap.  A workgroup owns 64 a-channels x (BT
+// b-channels x all taps); the (b-tile, tap) pairs are dealt round-robin to its four waves (up to 9
+// each = 144 accumulator registers).  It walks a 32-pixel-wide column strip of one sample top to
+// bottom: the P row tile is double-buffered in LDS, the Q rows live in a ring of (kh-1)*dh+1+sh rows
+// so every input row is fetched once per strip, and the global loads of step p+1 are in flight in
+// registers while step p's MFMAs run.  Partial results of the (few hundred) workgroups that share an
+// output block go to a workspace [split][tap][a][b] and a second kernel adds them in a fixed order:
+// no atomics, bit-reproducible.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/unetmi.h"
+
+namespace unetmi {
+
+int api_fail(int code, const std::string& msg);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTQ = 32;          // pixels of a P row handled per step
+constexpr int kPPitch = 36;      // LDS pitch of a P row (4 x odd: the A-operand read is conflict-free)
+constexpr int kMaxQ = 12;        // Q elements staged per thread per step
+constexpr int kMaxPairs = 36;    // (b-tile, tap) pairs per workgroup = 4 waves x 9
+
+struct WgradArgs {
+    const float* p0;
+    const float* p1;
+    const float* q;
+    float* ws;
+    int N, A0, A1, A, B, PH, PW, QH, QW, kh, kw, sh, sw, ph, pw, dh, dw;
+    int BT;          // b-channels per workgroup (multiple of 16)
+    int qcols;       // staged columns of a Q row: (kTQ-1)*sw + (kw-1)*dw + 1
+    int qpitch;      // LDS pitch of a Q row (4 x odd)
+    int R;           // rows of the ring
+    int win;         // rows a step reads: (kh-1)*dh + 1
+    int nqc;         // column strips per sample
+    int strips, spw; // N*nqc, strips per workgroup
+    int ntaps, npairs;
+    int nq_items;    // sh*BT*qcols elements staged per step
+    int ring_bias;   // multiple of R added before the modulo so negative rows map consistently
+};
+
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+
+constexpr int kOob = (int)0x80000000;     // byte offset beyond any buffer: the load returns 0
+
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
+    extern __shared__ float lds[];
+    float* sP = lds;                               // [2][64][kPPitch]
+    float* sQ = lds + 2 * 64 * kPPitch;            // [R][BT][qpitch], then 256 floats nobody reads
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rowstride = g.BT * g.qpitch;
+    const int bb = blockIdx.y * g.BT;
+    // a-blocks enumerate 64-channel blocks of the first source, then of the second
+    const int nblk0 = (g.A0 + 63) >> 6;
+    const bool second = (int)blockIdx.z >= nblk0;
+    const int a_lo = (second ? (int)blockIdx.z - nblk0 : (int)blockIdx.z) * 64;   // first channel within its source
+    const int a_cnt = second ? g.A1 : g.A0;                                       // channels of that source
+    const int a_out = a_lo + (second ? g.A0 : 0);                                 // first row of dW
+    const float* psrc = second ? g.p1 : g.p0;
+
+    // this wave's (b-tile, tap) pairs
+    int pair_row[NT], pair_off[NT], pair_tap[NT], pair_bt[NT];
+    bool pair_ok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int idx = wave + 4 * j;
+        pair_ok[j] = idx < g.npairs;
+        const int ic = pair_ok[j] ? idx : 0;
+        const int bt = ic / g.ntaps, tap = ic - bt * g.ntaps;
+        const int r = tap / g.kw, s = tap - r * g.kw;
+        pair_row[j] = r * g.dh;
+        pair_off[j] = s * g.dw + bt * 16 * g.qpitch;
+        pair_tap[j] = tap;
+        pair_bt[j] = bt;
+    }
+    const int la = (lane & 15) * kPPitch + (lane >> 4);
+    const int lb = (lane & 15) * g.qpitch + (lane >> 4) * g.sw;
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int pq = tid & 31, pa = tid >> 5;                 // P element i: channel a_lo + pa + 8*i, pixel pq
+    const int dummy = g.R * rowstride + tid;
+
+    int buf = 0;
+    const int st_lo = blockIdx.x * g.spw, st_hi = min(st_lo + g.spw, g.strips);
+    for (int st = st_lo; st < st_hi; ++st) {
+        const int n = st / g.nqc, q0 = (st - n * g.nqc) * kTQ;
+        const auto rs_p = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(psrc + (size_t)n * a_cnt * g.PH * g.PW), 0, a_cnt * g.PH * g.PW * 4, 0x00020000);
+        const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(g.q + (size_t)n * g.B * g.QH * g.QW), 0, g.B * g.QH * g.QW * 4, 0x00020000);
+
+        int p_voff[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int a = a_lo + pa + 8 * i;
+            p_voff[i] = (a < a_cnt && q0 + pq < g.PW) ? (a * g.PH * g.PW + q0 + pq) * 4 : kOob;
+        }
+        // Q element i of this thread: flat index tid + 256*i over [sh rows][BT channels][qcols]
+        int q_voff[kMaxQ], q_lds[kMaxQ], q_rs[kMaxQ];
+#pragma unroll
+        for (int i = 0; i < kMaxQ; ++i) {
+            const int idx = tid + 256 * i;
+            const int per_row = g.BT * g.qcols;
+            const int rs = idx / per_row, rem = idx - rs * per_row;
+            const int bl = rem / g.qcols, cl = rem - bl * g.qcols;
+            const int b = bb + bl, col = q0 * g.sw - g.pw + cl;
+            const bool have = idx < g.nq_items;
+            q_rs[i] = have ? rs : -1;
+            q_lds[i] = bl * g.qpitch + cl;
+            q_voff[i] = (have && b < g.B && col >= 0 && col < g.QW) ? (b * g.QH * g.QW + col) * 4 : kOob;
+        }
+
+        float rp[8], rq[kMaxQ];
+        auto load_p = [&](int p) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rp[i] = buf_load(rs_p, p_voff[i], p * g.PW * 4);
+        };
+        auto store_p = [&](int b2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sP[(b2 * 64 + pa + 8 * i) * kPPitch + pq] = rp[i];
+        };
+        // rows y0 .. y0+sh-1 of Q
+        auto load_q = [&](int y0) {
+#pragma unroll
+            for (int i = 0; i < kMaxQ; ++i) {
+                const int y = y0 + q_rs[i];
+                rq[i] = buf_load(rs_q, ((unsigned)y < (unsigned)g.QH && q_rs[i] >= 0) ? q_voff[i] + y * g.QW * 4 : kOob, 0);
+            }
+        };
+        auto store_q = [&](int y0) {
+            const int s0 = (y0 + g.ring_bias) % g.R;             // wave-uniform
+#pragma unroll
+            for (int i = 0; i < kMaxQ; ++i) {
+                int slot = s0 + q_rs[i];
+                slot = slot >= g.R ? slot - g.R : slot;
+                sQ[q_rs[i] >= 0 ? slot * rowstride + q_lds[i] : dummy] = rq[i];
+            }
+        };
+
+        // prologue: the window of step 0 and its P tile
+        const int base0 = -g.ph;
+        for (int y = base0; y < base0 + g.win; y += g.sh) {
+            load_q(y);
+            store_q(y);
+        }
+        load_p(0);
+        store_p(buf);
+        __syncthreads();
+
+        int rowoff[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rowoff[j] = ((base0 + pair_row[j] + g.ring_bias) % g.R) * rowstride + pair_off[j] + lb;
+
+        for (int p = 0; p < g.PH; ++p) {
+            const int ynew = base0 + p * g.sh + g.win;       // first row step p+1 needs beyond this window
+            const bool more = p + 1 < g.PH;
+            if (more) {
+                load_p(p + 1);
+                load_q(ynew);
+            }
+            const float* tp = sP + buf * 64 * kPPitch + la;
+#pragma unroll
+            for (int gq = 0; gq < kTQ / 4; ++gq) {
+                float av[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) av[t] = tp[t * 16 * kPPitch + gq * 4];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float bv = sQ[rowoff[j] + gq * 4 * g.sw];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[j][t], 0, 0, 0);
+                }
+            }
+            if (more) {
+                store_p(buf ^ 1);
+                store_q(ynew);
+            }
+            __syncthreads();
+            buf ^= 1;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                rowoff[j] += g.sh * rowstride;
+                // the slot index is rowoff's multiple of rowstride; wrap when it passes the ring end
+                if (rowoff[j] - pair_off[j] - lb >= g.R * rowstride) rowoff[j] -= g.R * rowstride;
+            }
+        }
+    }
+
+    // partial block of dW -> ws[split][tap][a][b]
+    float* dst = g.ws + (size_t)blockIdx.x * g.ntaps * g.A * g.B;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        if (!pair_ok[j]) continue;
+        const int b = bb + pair_bt[j] * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int al = a_lo + t * 16 + 4 * (lane >> 4) + i;
+                if (al < a_cnt && b < g.B)
+                    dst[((size_t)pair_tap[j] * g.A + a_out - a_lo + al) * g.B + b] = acc[j][t][i];
+            }
+    }
+}
+
+// dW[a][b][tap] = sum over splits of ws[split][tap][a][b], fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                                           int ntaps, int A, int B) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total = ntaps * A * B;
+    if (i >= total) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + i];
+    const int tap = i / (A * B), ab = i - tap * (A * B);
+    dw[(size_t)ab * ntaps + tap] = s;
+}
+
+struct WgradPlan {
+    WgradArgs a;
+    int NT, splits, bgroups, ablocks;
+    size_t lds_bytes, ws_bytes;
+};
+
+static int round_pitch(int cols) {          // smallest 4 x odd >= cols
+    int p = (cols + 3) / 4;
+    if (!(p & 1)) ++p;
+    return p * 4;
+}
+
+static int plan_wgrad(int N, int A0, int A1, int B, int PH, int PW, int QH, int QW, int kh, int kw, int sh, int sw,
+                      int ph, int pw, int dh, int dw, WgradPlan* pl, std::string* why) {
+    WgradArgs& a = pl->a;
+    a = WgradArgs{};
+    a.N = N; a.A0 = A0; a.A1 = A1; a.A = A0 + A1; a.B = B; a.PH = PH; a.PW = PW; a.QH = QH; a.QW = QW;
+    a.kh = kh; a.kw = kw; a.sh = sh; a.sw = sw; a.ph = ph; a.pw = pw; a.dh = dh; a.dw = dw;
+    a.ntaps = kh * kw;
+    if ((long long)std::max(A0, A1) * PH * PW >= (1ll << 29) || (long long)B * QH * QW >= (1ll << 29)) {
+        *why = "one sample of an operand exceeds 2 GiB"; return UNETMI_E_UNSUPPORTED;
+    }
+    if (a.ntaps > kMaxPairs) { *why = "more than 36 kernel taps"; return UNETMI_E_UNSUPPORTED; }
+    a.qcols = (kTQ - 1) * sw + (kw - 1) * dw + 1;
+    a.qpitch = round_pitch(a.qcols);
+    a.win = (kh - 1) * dh + 1;
+    a.R = a.win + sh;
+    a.ring_bias = ((ph + a.R - 1) / a.R + 1) * a.R;
+    const int btiles = (B + 15) / 16;
+    int nbt = std::min(std::min(kMaxPairs / a.ntaps, btiles), 4);
+    while (nbt > 1 && sh * nbt * 16 * a.qcols > kMaxQ * 256) --nbt;
+    if (sh * nbt * 16 * a.qcols > kMaxQ * 256) { *why = "a row of the shifted operand does not fit the staging registers"; return UNETMI_E_UNSUPPORTED; }
+    a.BT = nbt * 16;
+    a.npairs = nbt * a.ntaps;
+    a.nq_items = sh * a.BT * a.qcols;
+    pl->NT = (a.npairs + 3) / 4;
+    pl->bgroups = (B + a.BT - 1) / a.BT;
+    pl->ablocks = (A0 + 63) / 64 + (A1 + 63) / 64;
+    a.nqc = (PW + kTQ - 1) / kTQ;
+    a.strips = N * a.nqc;
+    const int G = pl->bgroups * pl->ablocks;
+    int splits = std::min(a.strips, std::max(1, (768 + G - 1) / G));
+    a.spw = (a.strips + splits - 1) / splits;
+    pl->splits = (a.strips + a.spw - 1) / a.spw;
+    pl->lds_bytes = (size_t)(2 * 64 * kPPitch + a.R * a.BT * a.qpitch + 256) * sizeof(float);
+    if (pl->lds_bytes > 160 * 1024) { *why = "ring of input rows exceeds LDS"; return UNETMI_E_UNSUPPORTED; }
+    pl->ws_bytes = (size_t)pl->splits * a.ntaps * a.A * a.B * sizeof(float);
+    return UNETMI_OK;
+}
+
+template <int NT>
+static hipError_t launch_wgrad(const WgradPlan& pl, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<NT>), dim3(pl.splits, pl.bgroups, pl.ablocks), dim3(256), pl.lds_bytes, s, pl.a);
+    return hipGetLastError();
+}
+
+}  // namespace unetmi
+
+using namespace unetmi;
+
+extern "C" {
+
+static int wgrad_plan_from_desc(const UnetmiConvDesc* d, WgradPlan* pl, const char* what) {
+    if (!d) return api_fail(UNETMI_E_BAD_ARG, std::string(what) + ": null descriptor");
+    if (d->N < 0 || d->C0 < 1 || d->C1 < 0 || d->K < 1 || d->H < 1 || d->W < 1 || d->OH < 1 || d->OW < 1 || d->kh < 1 ||
+        d->kw < 1 || d->sh < 1 || d->sw < 1 || d->dh < 1 || d->dw < 1 || d->ph < 0 || d->pw < 0)
+        return api_fail(UNETMI_E_BAD_DESC, std::string(what) + ": bad geometry");
+    if (d->in_mode == UNETMI_IN_ADD) return api_fail(UNETMI_E_UNSUPPORTED, std::string(what) + ": summed inputs are not built");
+    if (!d->transposed && d->C1 != 0) return api_fail(UNETMI_E_UNSUPPORTED, std::string(what) + ": concatenated input of a plain conv is not built");
+    std::string why;
+    const int N = std::max(d->N, 1);
+    const int rc = d->transposed
+        ? plan_wgrad(N, d->C0, d->C1, d->K, d->H, d->W, d->OH, d->OW, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw, pl, &why)
+        : plan_wgrad(N, d->K, 0, d->C0, d->OH, d->OW, d->H, d->W, d->kh, d->kw, d->sh, d->sw, d->ph, d->pw, d->dh, d->dw, pl, &why);
+    if (rc) return api_fail(rc, std::string(what) + ": " + why);
+    return UNETMI_OK;
+}
+
+size_t unetmi_conv2d_wgrad_workspace_bytes(const UnetmiConvDesc* d) {
+    WgradPlan pl;
+    if (wgrad_plan_from_desc(d, &pl, "conv2d_wgrad_workspace_bytes")) return 0;
+    return pl.ws_bytes;
+}
+
+int unetmi_conv2d_wgrad(const UnetmiConvDesc* d, const float* in0, const float* in1, const float* dout, float* dweight,
+                        void* ws, size_t ws_bytes, void* stream) {
+    WgradPlan pl;
+    if (int rc = wgrad_plan_from_desc(d, &pl, "conv2d_wgrad")) return rc;
+    if (!dweight) return api_fail(UNETMI_E_BAD_ARG, "conv2d_wgrad: null gradient pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t wfloats = (size_t)(d->C0 + d->C1) * d->K * d->kh * d->kw;
+    if (d->N == 0) {
+        const hipError_t e = hipMemsetAsync(dweight, 0, wfloats * sizeof(float), s);
+        return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("conv2d_wgrad memset: ") + hipGetErrorString(e));
+    }
+    if (!in0 || !dout || !ws || (d->C1 > 0 && !in1)) return api_fail(UNETMI_E_BAD_ARG, "conv2d_wgrad: null tensor pointer");
+    if (ws_bytes < pl.ws_bytes) return api_fail(UNETMI_E_BAD_ARG, "conv2d_wgrad: workspace too small");
+    if (d->transposed) { pl.a.p0 = in0; pl.a.p1 = d->C1 > 0 ? in1 : in0; pl.a.q = dout; }
+    else               { pl.a.p0 = dout; pl.a.p1 = dout; pl.a.q = in0; }
+    pl.a.ws = static_cast<float*>(ws);
+    hipError_t e;
+    switch (pl.NT) {
+        case 1: e = launch_wgrad<1>(pl, s); break;
+        case 2: e = launch_wgrad<2>(pl, s); break;
+        case 3: e = launch_wgrad<3>(pl, s); break;
+        case 4: e = launch_wgrad<4>(pl, s); break;
+        case 5: e = launch_wgrad<5>(pl, s); break;
+        case 6: e = launch_wgrad<6>(pl, s); break;
+        case 7: e = launch_wgrad<7>(pl, s); break;
+        case 8: e = launch_wgrad<8>(pl, s); break;
+        default: e = launch_wgrad<9>(pl, s); break;
+    }
+    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("conv2d_wgrad launch: ") + hipGetErrorString(e));
+    const int total = pl.a.ntaps * pl.a.A * pl.a.B;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.a.ws, dweight, pl.splits,
+                       pl.a.ntaps, pl.a.A, pl.a.B);
+    e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("conv2d_wgrad reduce launch: ") + hipGetErrorString(e));
+}
+
+}  // extern "C"

@@ -1,0 +1,352 @@
+"""Train-mode forward/backward of the fused blocks, the flat-bucket Adam and the
+data-parallel training step.
+
+The reference trains its modules with stock autograd (there is no trainer in the
+repository); here every Encoder / Decoder block in ``train()`` mode is one
+``torch.autograd.Function`` whose forward and backward are HIP launches:
+
+    forward   conv (unetmi_conv2d_fwd, no epilogue) -> batch statistics
+              (unetmi_bn_train_stats) -> normalise + activation (unetmi_bn_act_fwd)
+    backward  unetmi_bn_act_bwd -> weight gradient (unetmi_conv2d_wgrad) and input
+              gradient (unetmi_conv2d_fwd on the gradient with the transposed flag
+              flipped: same weight tensor, conv <-> transposed conv)
+
+Autograd itself only routes tensors between blocks (skip connections, gradient
+accumulation).  Parameters and gradients can be flattened into single buckets
+(``FlatAdam``), so the data-parallel exchange is ONE all-reduce over RCCL and the
+optimizer is one kernel.
+"""
+
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check
+from .ops import conv2d_fwd, conv_out_size, make_desc, pack_conv_weights
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    """One growing scratch buffer per device (contents never outlive a launch sequence)."""
+    buf = _ws_cache.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[device] = buf
+    return buf
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dense(t, what):
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError("{} must be a contiguous fp32 device tensor".format(what))
+
+
+# ---------------------------------------------------------------------------------------
+# thin wrappers of the C ABI
+# ---------------------------------------------------------------------------------------
+def bn_train_stats(z, eps, momentum, running_mean, running_var):
+    """(mean, invstd) of z[N,C,...] over all but the channel axis; running stats updated in place."""
+    _dense(z, "bn_train_stats: z")
+    N, C = z.shape[0], z.shape[1]
+    HW = z.numel() // max(N * C, 1)
+    mean = torch.empty(C, dtype=torch.float32, device=z.device)
+    invstd = torch.empty_like(mean)
+    nbytes = _lib.lib.unetmi_bn_workspace_bytes(N, C, HW)
+    ws = _workspace(z.device, nbytes)
+    with torch.cuda.device(z.device):
+        check(_lib.lib.unetmi_bn_train_stats(N, C, HW, _ptr(z), eps, momentum, _ptr(running_mean), _ptr(running_var),
+                                             _ptr(mean), _ptr(invstd), _ptr(ws), ws.numel(), _stream(z)),
+              "unetmi_bn_train_stats")
+    return mean, invstd
+
+
+def bn_act_fwd(z, mean, invstd, gamma, beta, act, act_param):
+    _dense(z, "bn_act_fwd: z")
+    N, C = z.shape[0], z.shape[1]
+    HW = z.numel() // max(N * C, 1)
+    out = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        check(_lib.lib.unetmi_bn_act_fwd(N, C, HW, _ptr(z), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), act,
+                                         _ptr(act_param), _ptr(out), _stream(z)), "unetmi_bn_act_fwd")
+    return out
+
+
+def bn_act_bwd(dy, z, mean, invstd, gamma, beta, act, act_param, batch_stats):
+    """(dz, dgamma, dbeta, dbias).  dy may be a channel slice of a wider contiguous tensor."""
+    _dense(z, "bn_act_bwd: z")
+    N, C = z.shape[0], z.shape[1]
+    HW = z.numel() // max(N * C, 1)
+    if dy.shape != z.shape or dy.dtype != torch.float32 or not dy.is_cuda:
+        raise ValueError("bn_act_bwd: dy must match z")
+    inner = tuple(dy.stride()[1:]) == tuple(z.stride()[1:])
+    if not inner or (N > 1 and dy.stride(0) < C * HW):
+        dy = dy.contiguous()
+    batch_stride = dy.stride(0) if N > 1 else C * HW
+    dz = torch.empty_like(z)
+    dgamma, dbeta, dbias = (torch.empty(C, dtype=torch.float32, device=z.device) for _ in range(3))
+    nbytes = _lib.lib.unetmi_bn_workspace_bytes(N, C, HW)
+    ws = _workspace(z.device, nbytes)
+    with torch.cuda.device(z.device):
+        check(_lib.lib.unetmi_bn_act_bwd(N, C, HW, _ptr(dy), batch_stride, _ptr(z), _ptr(mean), _ptr(invstd),
+                                         _ptr(gamma), _ptr(beta), act, _ptr(act_param), int(batch_stats), _ptr(dz),
+                                         _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ws), ws.numel(), _stream(z)),
+              "unetmi_bn_act_bwd")
+    return dz, dgamma, dbeta, dbias
+
+
+def conv2d_wgrad(desc, in0, in1, dout):
+    """Weight gradient in torch layout for the layer ``desc`` describes."""
+    for t, n in ((in0, "in0"), (dout, "dout")):
+        _dense(t, "conv2d_wgrad: " + n)
+    if in1 is not None:
+        _dense(in1, "conv2d_wgrad: in1")
+    cin = desc.C0 + desc.C1
+    shape = (cin, desc.K, desc.kh, desc.kw) if desc.transposed else (desc.K, cin, desc.kh, desc.kw)
+    dw = torch.empty(shape, dtype=torch.float32, device=in0.device)
+    nbytes = _lib.lib.unetmi_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
+    if nbytes == 0:
+        raise _lib.UnetmiError("unetmi_conv2d_wgrad: " + _lib.last_error(), _lib.E_UNSUPPORTED)
+    ws = _workspace(in0.device, nbytes)
+    with torch.cuda.device(in0.device):
+        check(_lib.lib.unetmi_conv2d_wgrad(ctypes.byref(desc), _ptr(in0), _ptr(in1), _ptr(dout), _ptr(dw), _ptr(ws),
+                                           ws.numel(), _stream(in0)), "unetmi_conv2d_wgrad")
+    return dw
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        _dense(t, "adam_step: bucket")
+        if t.numel() != param.numel():
+            raise ValueError("adam_step: bucket sizes differ")
+    with torch.cuda.device(param.device):
+        check(_lib.lib.unetmi_adam_step(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), lr,
+                                        beta1, beta2, eps, weight_decay, grad_scale, step, _stream(param)),
+              "unetmi_adam_step")
+    torch.autograd.graph.increment_version(param)
+
+
+# ---------------------------------------------------------------------------------------
+# packing weights on the device (parameters change every step)
+# ---------------------------------------------------------------------------------------
+_pack_index_cache = {}
+
+
+def device_pack_index(cin, geom, transposed, device):
+    """int64 gather map of unetmi_conv2d_pack_weights: packed = cat(weight.flatten(), [0])[map].
+    The pack is a permutation with zero padding, so the map is found once per layer shape by
+    packing the element numbers on the host."""
+    key = (cin, tuple(geom), int(transposed), str(device))
+    idx = _pack_index_cache.get(key)
+    if idx is None:
+        K, kh, kw = geom[0], geom[1], geom[2]
+        shape = (cin, K, kh, kw) if transposed else (K, cin, kh, kw)
+        numel = cin * K * kh * kw
+        if numel >= (1 << 24):
+            raise ValueError("weight tensor too large for the float-coded index map")
+        numbered = torch.arange(1, numel + 1, dtype=torch.float32).reshape(shape)
+        packed = pack_conv_weights(numbered, cin, 0, geom, [int(transposed), _lib.IN_SINGLE, _lib.ACT_NONE, 0])
+        idx = packed.round().long() - 1
+        idx[idx < 0] = numel                       # -> the appended zero
+        idx = idx.to(device)
+        _pack_index_cache[key] = idx
+    return idx
+
+
+def pack_on_device(weight, geom, transposed):
+    cin = weight.shape[0] if transposed else weight.shape[1]
+    idx = device_pack_index(cin, geom, transposed, weight.device)
+    flat = torch.cat([weight.detach().reshape(-1), weight.new_zeros(1)])
+    return flat[idx]
+
+
+def _plain_conv(x, x2, weight, bias, geom, transposed):
+    """conv / transposed conv + bias, nothing else."""
+    K = geom[0]
+    wpacked = pack_on_device(weight, geom, transposed)
+    ones = torch.ones(K, dtype=torch.float32, device=x.device)
+    zeros = torch.zeros_like(ones)
+    b = bias.detach() if bias is not None else zeros
+    mode = _lib.IN_SINGLE if x2 is None else _lib.IN_CONCAT
+    flags = [int(transposed), mode, _lib.ACT_NONE, 0]
+    try:
+        return conv2d_fwd(x, x2, wpacked, b, ones, zeros, None, None, None, geom, flags)
+    except _lib.UnetmiError as e:
+        if e.code != _lib.E_UNSUPPORTED or x2 is None:
+            raise
+    return conv2d_fwd(torch.cat([x, x2], dim=1), None, wpacked, b, ones, zeros, None, None, None, geom,
+                      [int(transposed), _lib.IN_SINGLE, _lib.ACT_NONE, 0])
+
+
+def _input_gradient(dz, weight, geom, transposed, in_hw):
+    """Gradient w.r.t. the (concatenated) input: the opposite kind of convolution of dz with the
+    same weight tensor.  geom/transposed describe the FORWARD layer, in_hw its input size."""
+    K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
+    cin = weight.shape[0] if transposed else weight.shape[1]
+    H, W = in_hw
+    if transposed:
+        g2 = [cin, kh, kw, sh, sw, ph, pw, dh, dw, 0, 0]          # plain conv, weight read as [K'=Cin][C'=Cout]
+    else:
+        OH, OW = dz.shape[2], dz.shape[3]
+        g2 = [cin, kh, kw, sh, sw, ph, pw, dh, dw,
+              H - conv_out_size(OH, kh, sh, ph, dh, 0, True), W - conv_out_size(OW, kw, sw, pw, dw, 0, True)]
+    dx = _plain_conv(dz, None, weight, None, g2, not transposed)
+    if tuple(dx.shape[2:]) != (H, W):
+        raise RuntimeError("input-gradient geometry mismatch: {} vs {}".format(tuple(dx.shape[2:]), (H, W)))
+    return dx
+
+
+class ConvNormAct(torch.autograd.Function):
+    """y = act(norm(conv(cat(x, skip)))) with train-mode BatchNorm2d (batch statistics), eval-mode
+    BatchNorm2d (running statistics, still differentiable) or no norm."""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight, bias, gamma, beta, cfg):
+        geom, transposed = cfg["geom"], cfg["transposed"]
+        z = _plain_conv(x, skip, weight, bias, geom, transposed)
+        K = geom[0]
+        dev = z.device
+        bn = cfg["bn"]
+        if bn is not None and cfg["batch_stats"]:
+            mean, invstd = bn_train_stats(z, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        elif bn is not None:
+            mean = bn.running_mean.detach()
+            invstd = torch.rsqrt(bn.running_var.detach() + bn.eps)
+        else:
+            mean = torch.zeros(K, dtype=torch.float32, device=dev)
+            invstd = torch.ones_like(mean)
+        g = gamma.detach() if gamma is not None else torch.ones(K, dtype=torch.float32, device=dev)
+        b = beta.detach() if beta is not None else torch.zeros(K, dtype=torch.float32, device=dev)
+        y = bn_act_fwd(z, mean, invstd, g, b, cfg["act"], cfg["act_param"])
+        ctx.cfg = cfg
+        ctx.in_hw = tuple(x.shape[2:])
+        ctx.c0 = x.shape[1]
+        ctx.has_affine = (gamma is not None, beta is not None)
+        ctx.save_for_backward(x, skip, weight, z, mean, invstd, g, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, skip, weight, z, mean, invstd, g, b = ctx.saved_tensors
+        cfg = ctx.cfg
+        geom, transposed = cfg["geom"], cfg["transposed"]
+        need = ctx.needs_input_grad
+        dz, dgamma, dbeta, dbias = bn_act_bwd(dy, z, mean, invstd, g, b, cfg["act"], cfg["act_param"],
+                                              cfg["bn"] is not None and cfg["batch_stats"])
+        dweight = None
+        if need[2]:
+            N, C0, H, W = x.shape
+            C1 = skip.shape[1] if skip is not None else 0
+            d = make_desc(N, C0, C1, H, W, geom, [int(transposed), _lib.IN_CONCAT if C1 else _lib.IN_SINGLE, 0, 0])
+            if transposed or skip is None:
+                dweight = conv2d_wgrad(d, x, skip, dz)
+            else:                                   # plain conv over a concatenation: not a case these models have
+                d = make_desc(N, C0 + C1, 0, H, W, geom, [0, _lib.IN_SINGLE, 0, 0])
+                dweight = conv2d_wgrad(d, torch.cat([x, skip], 1), None, dz)
+        dx = dskip = None
+        if need[0] or (skip is not None and need[1]):
+            dcat = _input_gradient(dz, weight, geom, transposed, ctx.in_hw)
+            if skip is None:
+                dx = dcat
+            else:
+                dx, dskip = dcat[:, :ctx.c0], dcat[:, ctx.c0:]
+        return (dx if need[0] else None, dskip if need[1] else None, dweight,
+                dbias if need[3] else None, dgamma if (ctx.has_affine[0] and need[4]) else None,
+                dbeta if (ctx.has_affine[1] and need[5]) else None, None)
+
+
+def conv_norm_act(conv, norm, act_code, act_param, x, skip=None):
+    """Differentiable fused block for nn.Conv2d / nn.ConvTranspose2d ``conv`` followed by ``norm``
+    (nn.BatchNorm2d, nn.Identity or None) and an activation given by its epilogue code."""
+    from .fused import FusedConv
+    geom, transposed = FusedConv(conv).geometry()
+    bn = norm if isinstance(norm, nn.BatchNorm2d) else None
+    if norm is not None and bn is None and not isinstance(norm, nn.Identity):
+        raise NotImplementedError("train-mode forward is built for BatchNorm2d blocks only (got {})".format(
+            type(norm).__name__))
+    if conv.groups != 1 or (isinstance(conv, nn.Conv2d) and conv.padding_mode != "zeros"):
+        raise NotImplementedError("train-mode forward: grouped or non-zero-padded convolutions are not built")
+    batch_stats = bn is not None and (bn.training or bn.running_mean is None)
+    if bn is not None and batch_stats and (bn.momentum is None or not bn.track_running_stats):
+        raise NotImplementedError("train-mode BatchNorm2d needs a numeric momentum and tracked running statistics")
+    cfg = dict(geom=geom, transposed=bool(transposed), bn=bn, batch_stats=batch_stats, act=act_code,
+               act_param=act_param)
+    gamma = bn.weight if bn is not None else None
+    beta = bn.bias if bn is not None else None
+    return ConvNormAct.apply(x, skip, conv.weight, conv.bias, gamma, beta, cfg)
+
+
+# ---------------------------------------------------------------------------------------
+# optimizer and data-parallel step
+# ---------------------------------------------------------------------------------------
+class FlatAdam:
+    """torch.optim.Adam semantics (lr, betas, eps, weight_decay; no amsgrad) over ONE flat fp32
+    bucket: parameters and their .grad become views of two contiguous device buffers, so the
+    data-parallel gradient exchange is a single all-reduce and the update is a single kernel."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdam: no parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError("FlatAdam: parameters must be fp32 tensors on one GPU")
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = 0
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.reshape(-1))
+                p.data = self.flat[off:off + n].view(p.shape)
+                p.grad = self.grad[off:off + n].view(p.shape)
+                off += n
+
+    def zero_grad(self):
+        self.grad.zero_()
+        off = 0
+        for p in self.params:                       # re-attach if something replaced .grad
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + n].view(p.shape)
+            off += n
+
+    def all_reduce(self, group=None):
+        """Sum the gradient bucket over the data-parallel group (RCCL); the mean is taken inside step()."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grad, group=group)
+            return dist.get_world_size(group)
+        return 1
+
+    def step(self, world_size=1):
+        self.step_count += 1
+        adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
+                  self.eps, self.weight_decay, 1.0 / world_size, self.step_count)
+
+
+def train_step(model, optimizer, x, target, group=None):
+    """One data-parallel step: train-mode forward, loss mean((mask - target)^2), backward,
+    all-reduce(mean) of the gradient bucket, Adam.  Returns the local loss (a device scalar)."""
+    optimizer.zero_grad()
+    loss = torch.mean((model(x) - target) ** 2)
+    loss.backward()
+    world = optimizer.all_reduce(group)
+    optimizer.step(world)
+    return loss.detach()
