@@ -1,6 +1,8 @@
 """Training-step kernels against torch CPU autograd (the arithmetic the reference trains with) and
 against the golden training step recorded from the reference."""
 
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -109,7 +111,9 @@ def test_adam_matches_torch(device):
         ref.grad = g * step
         opt.step()
         adam_step(p, (g * step).to(device), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, step)
-        assert_close(p - p0.to(device), ref.detach() - p0, tol=1e-5, what="update after step {}".format(step))
+        # p is bit-rounded at its own magnitude (~1), the update is ~1e-3: compare both at their scale
+        assert_close(p, ref.detach(), tol=2e-7, what="parameters after step {}".format(step))
+        assert_close(p - p0.to(device), ref.detach() - p0, tol=1e-3, what="update after step {}".format(step))
 
 
 def _narrow_pair(seed):
@@ -130,6 +134,7 @@ def test_train_step_matches_golden_and_oracle(device):
     ref, dev = _narrow_pair(11)
     xb = normal("unet_narrow/xb", (2, 2, 257, 29), seed=12)
     target = uniform("unet_narrow/target", (2, 1, 257, 29), 0.0, 1.0, seed=12)
+    ref_init = copy.deepcopy(ref)
     ref.train()
     opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-3)
     opt_ref.zero_grad()
@@ -147,31 +152,48 @@ def test_train_step_matches_golden_and_oracle(device):
     golden = load_golden("unet_narrow_trainstep")
     assert abs(loss.item() - float(golden["loss"])) <= 1e-5 * abs(float(golden["loss"]))
     assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
-    # gradients: tolerance relative to the largest gradient of the same KIND of tensor, so the conv
-    # biases (whose true gradient under train-mode BatchNorm is zero) are held to rounding level
+    # Gradients.  The bar is rel-err 1e-4 of the tensor's largest entry where fp32 backprop is that
+    # well conditioned; through the 2x32-pixel bottleneck with a batch of 2 the reference's own fp32
+    # gradients differ from exact (float64) arithmetic by up to ~6e-3, so there the device is held to
+    # three times the reference's own distance from the float64 result.
+    ref64 = copy.deepcopy(ref_init).double().train()
+    torch.mean((ref64(xb.double()) - target.double()) ** 2).backward()
+    exact = {k: p.grad for k, p in ref64.named_parameters()}
     gmax = max(g.abs().max().item() for g in grads_ref.values())
     for k, p in dev.named_parameters():
         g, want = p.grad.detach().cpu(), grads_ref[k]
         scale = max(want.abs().max().item(), 1e-3 * gmax)
-        err = (g - want).abs().max().item()
-        assert err <= 1e-4 * scale, "grad {}: err {:.3e} vs scale {:.3e}".format(k, err, scale)
+        cpu_err = (want.double() - exact[k]).abs().max().item()
+        tol = max(1e-4 * scale, 3.0 * cpu_err)
+        err = (g.double() - exact[k]).abs().max().item()
+        assert err <= tol, "grad {}: err {:.3e} vs tol {:.3e} (scale {:.3e})".format(k, err, tol, scale)
         gs = golden["grad/" + k]
         have = g.reshape(-1)[torch.from_numpy(sample_index(g.numel(), 8))].numpy()
-        assert np.abs(have - gs).max() <= 1e-4 * scale, "golden grad " + k
+        assert np.abs(have - gs).max() <= tol + cpu_err, "golden grad " + k
+    # Optimizer: torch's Adam applied on the CPU to the DEVICE gradients must land on the device's
+    # parameters (the first Adam step is lr * g / (|g| + eps), i.e. +-lr with the sign of g, so
+    # comparing against the step taken from the reference's own gradients would turn rounding-level
+    # differences in near-zero gradients into +-2 lr; gradient parity is established above).
+    twin = copy.deepcopy(ref_init).train()
+    for (k, p), (_, q) in zip(twin.named_parameters(), dev.named_parameters()):
+        p.grad = q.grad.detach().cpu().clone()
+    torch.optim.Adam(twin.parameters(), lr=1e-3).step()
     opt.step()
-    after_ref = ref.state_dict()
+    after_twin, after_ref = twin.state_dict(), ref.state_dict()
     for k, v in dev.state_dict().items():
-        want = after_ref[k].float()
+        have = v.detach().cpu().float()
         if k.endswith("num_batches_tracked"):
-            assert int(v.item()) == int(want.item())
+            assert int(v.item()) == int(after_ref[k].item()) == 1
             continue
-        delta_ref = want - before[k].float()
-        delta = v.detach().cpu().float() - before[k].float()
-        tol = 1e-3 * max(delta_ref.abs().max().item(), 1e-12) + 1e-6 * want.abs().max().item()
-        assert (delta - delta_ref).abs().max().item() <= tol, "post-step " + k
         gs = golden["post/" + k]
-        have = v.detach().cpu().float().reshape(-1)[torch.from_numpy(sample_index(v.numel(), 8))].numpy()
-        assert np.abs(have - gs).max() <= 1e-4 * max(np.abs(gs).max(), 1e-6) + 2e-6, "golden post-step " + k
+        sampled = have.reshape(-1)[torch.from_numpy(sample_index(have.numel(), 8))].numpy()
+        if k in grads_ref:
+            assert (have - after_twin[k]).abs().max().item() <= 2e-7 * max(have.abs().max().item(), 1.0), "Adam " + k
+            assert (have - after_ref[k]).abs().max().item() <= 2.001e-3, "post-step " + k
+            assert np.abs(sampled - gs).max() <= 2.001e-3, "golden post-step " + k
+        else:                                   # BatchNorm running statistics after one train-mode forward
+            assert_close(have, after_ref[k].float(), tol=1e-5, what="post-step " + k)
+            assert np.abs(sampled - gs).max() <= 1e-5 * max(np.abs(gs).max(), 1e-6), "golden post-step " + k
 
 
 def test_eval_after_training_uses_updated_weights(device):

@@ -218,6 +218,9 @@ class ConvNormAct(torch.autograd.Function):
         bn = cfg["bn"]
         if bn is not None and cfg["batch_stats"]:
             mean, invstd = bn_train_stats(z, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+            # the kernel wrote the running statistics through raw pointers: tell torch they changed
+            torch.autograd.graph.increment_version(bn.running_mean)
+            torch.autograd.graph.increment_version(bn.running_var)
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
         elif bn is not None:
@@ -339,6 +342,8 @@ class FlatAdam:
         self.step_count += 1
         adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
                   self.eps, self.weight_decay, 1.0 / world_size, self.step_count)
+        for p in self.params:                      # parameters keep their own version counters
+            torch.autograd.graph.increment_version(p)
 
 
 def train_step(model, optimizer, x, target, group=None):
