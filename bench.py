@@ -106,6 +106,86 @@ def cpu_baseline(threads):
                        "best of 5 after 2 warm-ups, torch {} CPU".format(torch.__version__))
 
 
+TRAIN_PER_GPU_BATCH = 8
+
+
+def cpu_train_baseline(threads):
+    import oracle
+    from unet_amd import seeded_fill_
+    torch.set_num_threads(threads)
+    net = oracle.UNet(*oracle.default_unet(c_in=2, c_last=1, f_dim=32)).train()
+    seeded_fill_(net, seed=0)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    x = synthetic_batch(4, 1234)
+    target = torch.rand((4, 1, F_BINS, T_PADDED), generator=torch.Generator().manual_seed(99))
+    best = float("inf")
+    for i in range(1 + 3):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        torch.mean((net(x) - target) ** 2).backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        if i >= 1:
+            best = min(best, dt)
+    return dict(value=4 * AUDIO_SECONDS / best, unit="audio-s/s", cores=threads, kind="port",
+                sample="oracle UNet train step (fwd, MSE, bwd, Adam), batch 4 x [2,257,509] fp32, best of 3 "
+                       "after 1 warm-up, torch {} CPU autograd".format(torch.__version__))
+
+
+def run_train(args, rank, world, dev):
+    """Data-parallel training step of the same UNet: train-mode forward, MSE to a U(0,1) target mask,
+    backward, ONE all-reduce of the flat gradient bucket over RCCL, Adam.  8 utterances per GPU."""
+    import unet_amd
+    from unet_amd.train import FlatAdam, train_step
+    if world > 1:
+        import torch.distributed as dist
+    net = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=32))
+    unet_amd.seeded_fill_(net, seed=0)
+    net.train().to(dev)
+    opt = FlatAdam(net.parameters(), lr=1e-3)
+    x = synthetic_batch(TRAIN_PER_GPU_BATCH, 1234 + rank).to(dev)
+    target = torch.rand((TRAIN_PER_GPU_BATCH, 1, F_BINS, T_PADDED),
+                        generator=torch.Generator().manual_seed(99 + rank)).to(dev)
+    for _ in range(args.warmup):
+        loss = train_step(net, opt, x, target)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(net, opt, x, target)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        return
+    flops = 3 * 64.34e9 * TRAIN_PER_GPU_BATCH * args.steps        # fwd + input-gradient + weight-gradient convs
+    achieved = flops / elapsed / 1e12
+    result = {
+        "metric": "audio-seconds trained/sec (whole node), UNet train step fp32",
+        "value": world * TRAIN_PER_GPU_BATCH * AUDIO_SECONDS * args.steps / elapsed, "unit": "audio-s/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "UNet default config, train() step: forward with batch statistics, "
+                               "mean((mask-target)^2), backward, all-reduce(mean) of one flat gradient bucket, "
+                               "Adam(1e-3); batch 8 x [2,257,509] fp32 per GPU",
+                   "per_gpu_batch": TRAIN_PER_GPU_BATCH, "global_batch": world * TRAIN_PER_GPU_BATCH,
+                   "gflop_per_utterance": 3 * 64.34, "parallelism": "data-parallel x{}".format(world),
+                   "final_loss": float(loss.item())},
+        "roofline": {"bound": "mfma", "kernel": "whole step (conv fwd + dgrad + wgrad)", "achieved": achieved,
+                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                     "traffic": None},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_train_baseline(torch.get_num_threads())
+    print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +193,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="per-layer times of the last step on stderr")
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward: the headline metric (default); train: the data-parallel training step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +208,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.mode == "train":
+        run_train(args, rank, world, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import unet_amd
     from unet_amd import ops

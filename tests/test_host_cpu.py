@@ -141,3 +141,60 @@ def test_shard_batch_covers_everything_once():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+TRAIN_WORKER = r'''
+import os, sys, copy, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import oracle
+from unet_amd.train import FlatBucket
+from unet_amd.seeding import seeded_fill_, normal, uniform
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+net = oracle.UNet(*oracle.default_unet(f_dim=8)).train()
+seeded_fill_(net, seed=5)
+twin = copy.deepcopy(net)                      # untouched copy for the single-process answer
+x = normal("dp/x", (4, 2, 257, 13), seed=5)
+target = uniform("dp/t", (4, 1, 257, 13), 0.0, 1.0, seed=5)
+per = x.shape[0] // world
+# every rank: its own shard, per-replica BatchNorm statistics, gradients into the flat bucket
+bucket = FlatBucket(net.parameters())
+assert all(p.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())
+bucket.zero_grad()
+torch.mean((net(x[rank * per:(rank + 1) * per]) - target[rank * per:(rank + 1) * per]) ** 2).backward()
+n = bucket.all_reduce()
+assert n == world
+mean_grad = bucket.grad / n
+# expected: arithmetic mean over shards of the per-shard gradients, computed serially
+want = torch.zeros_like(bucket.grad)
+for r in range(world):
+    m = copy.deepcopy(twin)
+    torch.mean((m(x[r * per:(r + 1) * per]) - target[r * per:(r + 1) * per]) ** 2).backward()
+    want += torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+want /= world
+err = (mean_grad - want).abs().max().item()
+assert err <= 1e-6 * want.abs().max().item() + 1e-12, err
+# every rank holds the same averaged bucket
+gathered = [torch.zeros_like(mean_grad) for _ in range(world)]
+dist.all_gather(gathered, mean_grad)
+assert all(torch.equal(g, gathered[0]) for g in gathered)
+# zero_grad re-attaches views if an optimizer replaced .grad
+next(iter(net.parameters())).grad = None
+bucket.zero_grad()
+assert next(iter(net.parameters())).grad.data_ptr() == bucket.grad.data_ptr()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_gradient_bucket_all_reduce_two_ranks_gloo(tmp_path):
+    """Data-parallel training exchange: ONE all-reduce over the flat gradient bucket gives the
+    mean of the per-shard gradients (BatchNorm statistics stay per replica)."""
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29519", str(script), ROOT],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2

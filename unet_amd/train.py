@@ -293,25 +293,21 @@ def conv_norm_act(conv, norm, act_code, act_param, x, skip=None):
 # ---------------------------------------------------------------------------------------
 # optimizer and data-parallel step
 # ---------------------------------------------------------------------------------------
-class FlatAdam:
-    """torch.optim.Adam semantics (lr, betas, eps, weight_decay; no amsgrad) over ONE flat fp32
-    bucket: parameters and their .grad become views of two contiguous device buffers, so the
-    data-parallel gradient exchange is a single all-reduce and the update is a single kernel."""
+class FlatBucket:
+    """Parameters and their .grad as views of two contiguous fp32 buffers, so the data-parallel
+    gradient exchange is a single all-reduce.  Device-agnostic (the host logic is exercised with
+    gloo on CPU tensors); the optimizer on top of it is device-only."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
-            raise ValueError("FlatAdam: no parameters")
+            raise ValueError("FlatBucket: no parameters")
         dev = self.params[0].device
-        if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in self.params):
-            raise ValueError("FlatAdam: parameters must be fp32 tensors on one GPU")
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError("FlatBucket: parameters must be fp32 tensors on one device")
         total = sum(p.numel() for p in self.params)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros_like(self.flat)
-        self.exp_avg = torch.zeros_like(self.flat)
-        self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.step_count = 0
         off = 0
         with torch.no_grad():
             for p in self.params:
@@ -331,12 +327,27 @@ class FlatAdam:
             off += n
 
     def all_reduce(self, group=None):
-        """Sum the gradient bucket over the data-parallel group (RCCL); the mean is taken inside step()."""
+        """Sum the gradient bucket over the data-parallel group (RCCL on GPUs); returns the group
+        size, by which the caller divides (FlatAdam.step folds the division into the update)."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.grad, group=group)
             return dist.get_world_size(group)
         return 1
+
+
+class FlatAdam(FlatBucket):
+    """torch.optim.Adam semantics (lr, betas, eps, weight_decay; no amsgrad) over the flat bucket:
+    the update of all parameters is one kernel."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params)
+        if self.flat.device.type != "cuda":
+            raise ValueError("FlatAdam: parameters must live on the GPU")
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = 0
 
     def step(self, world_size=1):
         self.step_count += 1
