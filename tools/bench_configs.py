@@ -1,0 +1,94 @@
+"""Throughput of the secondary workloads on one MI355X (bench.py measures the headline one):
+
+    python tools/bench_configs.py [--steps K] [--warmup W] [--batch B] [--only NAME]
+
+  unet20   cRFUNet.UNet20 forward + ratio-filter application, per-GPU share (32) of the batch of 256
+           that is sharded over 8 GPUs, [32,14,257,509] fp32
+  resunet  ResUNet forward, [32,4,257,501] fp32
+  dsunet   DSUNet (UDSS.set_size(45, 8) table) forward, sf [32,8,257,512], SV [32,4,514], theta [32,2]
+
+One JSON line per workload: audio-seconds/s (4.0 s per utterance), ms per step and the algorithmic
+GFLOP per utterance it implies.  Run it under ``rocprofv3 --kernel-trace --stats`` for the per-kernel
+times behind the bandwidth figures of the depthwise / mask kernels.
+"""
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+AUDIO_SECONDS = 4.0
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    import unet_amd
+    from unet_amd.ops import crf_apply
+    dev = torch.device("cuda", 0)
+    B = args.batch
+    g = torch.Generator().manual_seed(4321)
+
+    def report(name, sec, gflop, workload):
+        print(json.dumps({"workload": name, "value": B * AUDIO_SECONDS / sec, "unit": "audio-s/s",
+                          "ms_per_step": 1e3 * sec, "batch": B, "dtype": "f32",
+                          "gflop_per_utterance": gflop, "tflops": gflop * B / sec / 1e3,
+                          "config": workload}), flush=True)
+
+    with torch.no_grad():
+        if args.only in (None, "unet20"):
+            net = unet_amd.UNet20()
+            unet_amd.seeded_fill_(net, seed=21)
+            net.T = 509
+            net.eval().to(dev)
+            x = torch.rand((B, 14, 257, 509), generator=g).to(dev)
+            X = torch.view_as_complex(torch.randn((B, 4, 257, 509, 2), generator=g).contiguous()).to(dev)
+            sec = timed(lambda: crf_apply(net(x), X), args.steps, args.warmup)
+            report("unet20", sec, 76.65, "cRFUNet.UNet20(c_in=14, c_out=4) forward at T=509 + ratio-filter "
+                                         "application, one GPU's share of a batch of 256 over 8 GPUs")
+            del net, x, X
+        if args.only in (None, "resunet"):
+            net = unet_amd.ResUNet()
+            unet_amd.seeded_fill_(net, seed=31)
+            net.eval().to(dev)
+            x = torch.randn((B, 4, 257, 501), generator=g).to(dev)
+            sec = timed(lambda: net(x), args.steps, args.warmup)
+            report("resunet", sec, 46.0, "ResUNet() forward, [B,4,257,501]")
+            del net, x
+        if args.only in (None, "dsunet"):
+            net = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8))
+            unet_amd.seeded_fill_(net, seed=41)
+            net.eval().to(dev)
+            sf = torch.randn((B, 8, 257, 512), generator=g).to(dev)
+            SV = torch.randn((B, 4, 514), generator=g).to(dev)
+            ang = torch.rand((B,), generator=g) * 2 * math.pi
+            theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1).to(dev)
+            sec = timed(lambda: net(sf, SV, theta), args.steps, args.warmup)
+            report("dsunet", sec, 129.76, "DSUNet(UDSS table, model_complexity 45, 8 inputs) forward, "
+                                          "sf [B,8,257,512], SV [B,4,514], theta [B,2]")
+
+
+if __name__ == "__main__":
+    main()

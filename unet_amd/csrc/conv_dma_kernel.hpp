@@ -136,15 +136,15 @@ __global__ __launch_bounds__(256, NG == 1 ? 3 : 2) void conv_dma_kernel(const Co
 
     auto open_chunk = [&](int chunk, int buf) {      // point the DMA state at (chunk -> LDS buffer buf)
         const bool live = chunk < p.nchunk && !(ABLATE(8) && chunk > 0);
-        const int ci_base = chunk * p.ci_chunk;
         int ch;
         long long first;
         const float* base = p.in0;
-        if (p.in_mode == UNETMI_IN_CONCAT && ci_base >= p.C0) {
-            base = p.in1; ch = min(p.ci_chunk, p.Ctot - ci_base); first = (long long)n * p.C1 + (ci_base - p.C0);
+        if (chunk >= p.nchunk0) {                    // second source of a concatenation
+            const int ci_base = (chunk - p.nchunk0) * p.ci_chunk;
+            base = p.in1; ch = min(p.ci_chunk, p.C1 - ci_base); first = (long long)n * p.C1 + ci_base;
         } else {
-            const int cend = (p.in_mode == UNETMI_IN_CONCAT) ? p.C0 : p.Ctot;
-            ch = min(p.ci_chunk, cend - ci_base); first = (long long)n * p.C0 + ci_base;
+            const int ci_base = chunk * p.ci_chunk;
+            ch = min(p.ci_chunk, p.C0 - ci_base); first = (long long)n * p.C0 + ci_base;
         }
         side.in_base = base + first * HW;
         side.in_bytes = live ? ch * HW * 4 : 0;

@@ -21,7 +21,7 @@ struct ConvArgs {
     int w_nphase, w_in_step, w_tap_step;
     int w_ntap[kMaxPhase], w_base[kMaxPhase], w_nout[kMaxPhase];
     int w_colmin;
-    int ci_chunk, nchunk, NB, nco_blk, TI;
+    int ci_chunk, nchunk, nchunk0, NB, nco_blk, TI;
     int nrows, ncols, plane, in_tile_floats, w_tile_floats;
     int wtaps[kMaxPhase];
     unsigned long long w_phase_off[kMaxPhase];
@@ -370,31 +370,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 
     auto prefetch = [&](int chunk) {
         const bool live = chunk < p.nchunk && !(ABLATE(8) && chunk > 0);   // else: every load out of range
-        const int ci_base = chunk * p.ci_chunk;
-        // source 0: in0 channels [ci_base, ...) ; source 1: in1 (concat tail, or the addend)
-        int ch0, ch1 = 0;
-        long long first0, first1 = 0;
-        int shift1 = 0;                               // byte shift of source-1 offsets
-        if (p.in_mode == UNETMI_IN_CONCAT) {
-            if (TWO) {
-                ch0 = min(max(p.C0 - ci_base, 0), p.ci_chunk);
-                first0 = (long long)n * p.C0 + ci_base;
-                ch1 = p.C1;                           // addressed from in1's channel 0 of image n
-                first1 = (long long)n * p.C1;
-                shift1 = (ci_base - p.C0) * HW * 4;   // negative offsets wrap to out-of-range
-            } else if (ci_base < p.C0) {              // chunk wholly inside in0 (launcher guarantees)
-                ch0 = min(p.ci_chunk, p.C0 - ci_base);
-                first0 = (long long)n * p.C0 + ci_base;
-            } else {                                  // chunk wholly inside in1
-                ch0 = min(p.ci_chunk, p.Ctot - ci_base);
-                first0 = (long long)n * p.C1 + (ci_base - p.C0);
-            }
-        } else {
-            ch0 = min(p.ci_chunk, p.Ctot - ci_base);
-            first0 = (long long)n * p.C0 + ci_base;
-            if (TWO) { ch1 = ch0; first1 = first0; }
-        }
-        const float* base0 = (p.in_mode == UNETMI_IN_CONCAT && !TWO && ci_base >= p.C0) ? p.in1 : p.in0;
+        // source 0: the tensor this chunk streams from (a concatenation is chunked per source);
+        // source 1: the addend of a summed input
+        const bool second = chunk >= p.nchunk0;
+        const int ci_base = (second ? chunk - p.nchunk0 : chunk) * p.ci_chunk;
+        const int csrc = second ? p.C1 : p.C0;
+        const int ch0 = max(min(p.ci_chunk, csrc - ci_base), 0);
+        const long long first0 = (long long)n * csrc + ci_base;
+        const int ch1 = (TWO && p.in_mode == UNETMI_IN_ADD) ? ch0 : 0;
+        const long long first1 = first0;
+        const int shift1 = 0;
+        const float* base0 = second ? p.in1 : p.in0;
         const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(base0 + first0 * HW), 0, live ? ch0 * HW * 4 : 0, 0x00020000);
 #pragma unroll

@@ -57,7 +57,7 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
         p.blk_end[q] = total;
     }
     p.w_colmin = pl.w_colmin;
-    p.ci_chunk = pl.ci_chunk; p.nchunk = pl.nchunk; p.NB = pl.NB; p.nco_blk = pl.nco_blk; p.TI = pl.TI;
+    p.ci_chunk = pl.ci_chunk; p.nchunk = pl.nchunk; p.nchunk0 = pl.nchunk0; p.NB = pl.NB; p.nco_blk = pl.nco_blk; p.TI = pl.TI;
     p.nrows = pl.nrows; p.ncols = pl.ncols; p.plane = pl.plane;
     p.in_tile_floats = pl.in_tile_floats; p.w_tile_floats = pl.w_tile_floats; p.njt = pl.njt;
     p.magic_ncols = magic_u32(pl.ncols); p.magic_nrows = magic_u32(pl.nrows);
@@ -68,7 +68,7 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
 #endif
     if (total == 0) return hipSuccess;
 
-    // two loads per input element: the skip add, or a concat whose channel chunks straddle C0
+    // two loads per input element: the skip add
     const bool two = needs_two_loads(d, pl);
     bool done = false;
     if (two || g_force_staged) {

@@ -77,6 +77,7 @@ struct ConvPlan {
     int Ctot = 0;          // channels summed over (C0+C1 for concat, C0 otherwise)
     int ci_chunk = 2;      // channels staged per LDS pass (even)
     int nchunk = 1;
+    int nchunk0 = 1;       // chunks of the first source; a chunk never mixes channels of in0 and in1
     int NB = 64;           // output channels per workgroup (32 or 64)
     int nco_blk = 1;
     int WM = 2, WN = 2;    // wave grid inside the workgroup (WM*WN = 4)
@@ -177,15 +178,18 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
         *err = "one channel pair does not fit in LDS for this geometry"; return false;
     }
     // among chunk sizes in (max/2, max], take the one that pads the channel
-    // count the least (padding is MFMA work on zeros); ties go to the larger
+    // count the least (padding is MFMA work on zeros); ties go to the larger.
+    // A concatenated input is chunked per source, so that every chunk streams from one tensor.
+    const bool cat = d.in_mode == UNETMI_IN_CONCAT;
+    const int prs0 = cat ? (d.C0 + 1) / 2 : cpad / 2, prs1 = cat ? (d.C1 + 1) / 2 : 0;
     int pairs = max_pairs, best_total = 1 << 30;
     for (int p = max_pairs; p >= std::max(1, max_pairs / 2 + 1); --p) {
-        const int total = ((cpad / 2 + p - 1) / p) * p;
+        const int total = ((prs0 + p - 1) / p + (prs1 + p - 1) / p) * p;
         if (total < best_total) { best_total = total; pairs = p; }
     }
-    const int nchunk = (cpad / 2 + pairs - 1) / pairs;
     pl->ci_chunk = 2 * pairs;
-    pl->nchunk = nchunk;
+    pl->nchunk0 = (prs0 + pairs - 1) / pairs;
+    pl->nchunk = pl->nchunk0 + (prs1 + pairs - 1) / pairs;
 
     size_t off = 0;
     for (int a = 0; a < pl->h.nphase; ++a) {
@@ -206,10 +210,23 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     return true;
 }
 
-// Two loads per input element are needed for the skip add and for a concat whose
-// channel chunks straddle the boundary between the two sources.
-inline bool needs_two_loads(const UnetmiConvDesc& d, const ConvPlan& pl) {
-    return d.in_mode == UNETMI_IN_ADD || (d.in_mode == UNETMI_IN_CONCAT && d.C0 % pl.ci_chunk != 0);
+// Two loads per input element are needed for the skip add only.
+inline bool needs_two_loads(const UnetmiConvDesc& d, const ConvPlan&) {
+    return d.in_mode == UNETMI_IN_ADD;
+}
+
+// Channel of the (concatenated) input that position i of chunk `chunk` holds, or -1 for padding.
+inline int chunk_channel(const UnetmiConvDesc& d, const ConvPlan& pl, int chunk, int i) {
+    if (d.in_mode != UNETMI_IN_CONCAT) {
+        const int c = chunk * pl.ci_chunk + i;
+        return c < pl.Ctot ? c : -1;
+    }
+    if (chunk < pl.nchunk0) {
+        const int c = chunk * pl.ci_chunk + i;
+        return c < d.C0 ? c : -1;
+    }
+    const int c = (chunk - pl.nchunk0) * pl.ci_chunk + i;
+    return c < d.C1 ? d.C0 + c : -1;
 }
 
 }  // namespace unetmi

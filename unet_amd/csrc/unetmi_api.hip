@@ -78,10 +78,10 @@ int unetmi_conv2d_pack_weights(const UnetmiConvDesc* d, const float* w, float* p
                                 const int ky = pl.h.kidx0[a] + th * pl.h.kidx_step[a];
                                 const int kx = pl.w.kidx0[g] + tw * pl.w.kidx_step[g];
                                 for (int hf = 0; hf < 2; ++hf) {
-                                    const int ci = chunk * pl.ci_chunk + cp * 2 + hf;
+                                    const int ci = chunk_channel(*d, pl, chunk, cp * 2 + hf);
                                     for (int nb = 0; nb < pl.NB; ++nb, ++dst) {
                                         const int co = cb * pl.NB + nb;
-                                        if (ci >= C || co >= K) continue;
+                                        if (ci < 0 || co >= K) continue;
                                         const size_t src = d->transposed
                                             ? (((size_t)ci * K + co) * KH + ky) * KW + kx
                                             : (((size_t)co * C + ci) * KH + ky) * KW + kx;
@@ -112,8 +112,7 @@ int unetmi_conv2d_fwd(const UnetmiConvDesc* d, const float* in0, const float* in
     if (pl.lds_bytes_dma > 80 * 1024) return fail(UNETMI_E_UNSUPPORTED, "LDS images exceed 80 KB");
     if (!pl.direct && pl.NG == 2 && needs_two_loads(*d, pl))
         return fail(UNETMI_E_UNSUPPORTED,
-                    "two-source input (add, or concat with C0 not a multiple of the channel chunk) on a "
-                    "time-stride-2 transposed conv: combine the inputs first");
+                    "summed two-source input on a time-stride-2 transposed conv: add the inputs first");
     const hipError_t e = (pl.direct ? launch_direct_conv : launch_conv_mfma)(*d, pl, in0, in1, wpacked, bias, scale, shift, act_param,
                                           gate, residual, out, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(UNETMI_E_HIP, std::string("conv launch: ") + hipGetErrorString(e));

@@ -124,6 +124,7 @@ class FusedConv:
             weight = c.weight.permute(0, 1, 3, 2) if self.swap_hw else c.weight
             wpacked = pack_conv_weights(weight, c.in_channels, 0, geom,
                                         [transposed, _lib.IN_SINGLE, code, 0]).to(device)
+            self._weight_for_split, self._split_images = weight.detach(), {}
             f32 = dict(dtype=torch.float32, device=device)
             bias = (c.bias.detach().to(**f32) if c.bias is not None else torch.zeros(K, **f32)).contiguous()
             n = self.norm
@@ -148,6 +149,18 @@ class FusedConv:
         self._key = key
         return self._state
 
+    def _image(self, st, C0, C1, mode):
+        """Packed weights for this call: a concatenated input is chunked per source inside the
+        kernel, so its image depends on where the channels split (cached per split)."""
+        if mode != _lib.IN_CONCAT:
+            return st["wpacked"]
+        img = self._split_images.get((C0, C1))
+        if img is None:
+            img = pack_conv_weights(self._weight_for_split, C0, C1, st["geom"],
+                                    [st["transposed"], _lib.IN_CONCAT, st["act"], 0]).to(st["wpacked"].device)
+            self._split_images[(C0, C1)] = img
+        return img
+
     # -- launch ----------------------------------------------------------------------
     def __call__(self, x, x2=None, in_mode=None, gate=None, residual=None, epilogue=True):
         """x2 with in_mode IN_CONCAT (default when x2 is given) or IN_ADD.
@@ -161,20 +174,21 @@ class FusedConv:
         cin = x.shape[1] + (x2.shape[1] if (x2 is not None and mode == _lib.IN_CONCAT) else 0)
         if cin != self.conv.in_channels:
             raise RuntimeError("expected {} input channels, got {}".format(self.conv.in_channels, cin))
+        wimg = self._image(st, x.shape[1], x2.shape[1] if x2 is not None else 0, mode)
         if epilogue:
             try:
-                return conv2d_fwd(x, x2, st["wpacked"], st["bias"], st["scale"], st["shift"],
+                return conv2d_fwd(x, x2, wimg, st["bias"], st["scale"], st["shift"],
                                   st["act_param"], gate, residual, st["geom"],
                                   [st["transposed"], mode, st["act"], int(self.act_first)])
             except _lib.UnetmiError as e:
                 if e.code != _lib.E_UNSUPPORTED or x2 is None:
                     raise
-            # the one shape the kernels do not take two sources for (see unetmi_conv2d_fwd):
-            # form the combined input once, then run the single-source kernel
+            # the one case the kernels do not take two sources for (a summed input on a
+            # time-stride-2 transposed conv): form the combined input, run the single-source kernel
             merged = torch.cat([x, x2], dim=1) if mode == _lib.IN_CONCAT else x + x2
             return conv2d_fwd(merged, None, st["wpacked"], st["bias"], st["scale"], st["shift"],
                               st["act_param"], gate, residual, st["geom"],
                               [st["transposed"], _lib.IN_SINGLE, st["act"], int(self.act_first)])
         ones = torch.ones_like(st["bias"])
-        return conv2d_fwd(x, x2, st["wpacked"], st["bias"], ones, torch.zeros_like(ones), None, gate,
+        return conv2d_fwd(x, x2, wimg, st["bias"], ones, torch.zeros_like(ones), None, gate,
                           residual, st["geom"], [st["transposed"], mode, _lib.ACT_NONE, 0])

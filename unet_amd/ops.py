@@ -44,6 +44,8 @@ def make_desc(N, C0, C1, H, W, geom, flags, act_pc=0, has_gate=0, has_residual=0
 def pack_conv_weights(weight, C0, C1, geom, flags):
     """Host-side repack of a torch-layout weight into the kernel's image
     (unetmi_conv2d_pack_weights).  Returns a CPU float32 tensor."""
+    flags = list(flags)
+    flags[1] = _lib.IN_CONCAT if C1 else _lib.IN_SINGLE
     d = make_desc(1, C0, C1, 64, 64, geom, flags)
     # H/W do not enter the image; give the descriptor any consistent sizes
     d.H = d.W = 64

@@ -141,11 +141,11 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
 _pack_index_cache = {}
 
 
-def device_pack_index(cin, geom, transposed, device):
+def device_pack_index(cin, geom, transposed, device, c1=0):
     """int64 gather map of unetmi_conv2d_pack_weights: packed = cat(weight.flatten(), [0])[map].
     The pack is a permutation with zero padding, so the map is found once per layer shape by
     packing the element numbers on the host."""
-    key = (cin, tuple(geom), int(transposed), str(device))
+    key = (cin, c1, tuple(geom), int(transposed), str(device))
     idx = _pack_index_cache.get(key)
     if idx is None:
         K, kh, kw = geom[0], geom[1], geom[2]
@@ -154,7 +154,7 @@ def device_pack_index(cin, geom, transposed, device):
         if numel >= (1 << 24):
             raise ValueError("weight tensor too large for the float-coded index map")
         numbered = torch.arange(1, numel + 1, dtype=torch.float32).reshape(shape)
-        packed = pack_conv_weights(numbered, cin, 0, geom, [int(transposed), _lib.IN_SINGLE, _lib.ACT_NONE, 0])
+        packed = pack_conv_weights(numbered, cin - c1, c1, geom, [int(transposed), _lib.IN_SINGLE, _lib.ACT_NONE, 0])
         idx = packed.round().long() - 1
         idx[idx < 0] = numel                       # -> the appended zero
         idx = idx.to(device)
@@ -162,9 +162,11 @@ def device_pack_index(cin, geom, transposed, device):
     return idx
 
 
-def pack_on_device(weight, geom, transposed):
+def pack_on_device(weight, geom, transposed, c1=0):
+    """c1: channels of the second tensor when the layer reads a concatenation (the kernel chunks
+    the channels per source, so the image depends on the split)."""
     cin = weight.shape[0] if transposed else weight.shape[1]
-    idx = device_pack_index(cin, geom, transposed, weight.device)
+    idx = device_pack_index(cin, geom, transposed, weight.device, c1)
     flat = torch.cat([weight.detach().reshape(-1), weight.new_zeros(1)])
     return flat[idx]
 
@@ -172,7 +174,7 @@ def pack_on_device(weight, geom, transposed):
 def _plain_conv(x, x2, weight, bias, geom, transposed):
     """conv / transposed conv + bias, nothing else."""
     K = geom[0]
-    wpacked = pack_on_device(weight, geom, transposed)
+    wpacked = pack_on_device(weight, geom, transposed, x2.shape[1] if x2 is not None else 0)
     ones = torch.ones(K, dtype=torch.float32, device=x.device)
     zeros = torch.zeros_like(ones)
     b = bias.detach() if bias is not None else zeros
@@ -183,8 +185,8 @@ def _plain_conv(x, x2, weight, bias, geom, transposed):
     except _lib.UnetmiError as e:
         if e.code != _lib.E_UNSUPPORTED or x2 is None:
             raise
-    return conv2d_fwd(torch.cat([x, x2], dim=1), None, wpacked, b, ones, zeros, None, None, None, geom,
-                      [int(transposed), _lib.IN_SINGLE, _lib.ACT_NONE, 0])
+    return conv2d_fwd(torch.cat([x, x2], dim=1), None, pack_on_device(weight, geom, transposed), b, ones, zeros,
+                      None, None, None, geom, [int(transposed), _lib.IN_SINGLE, _lib.ACT_NONE, 0])
 
 
 def _input_gradient(dz, weight, geom, transposed, in_hw):
