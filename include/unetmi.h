@@ -141,6 +141,20 @@ int unetmi_dwconv2d_fwd(int N, int C, int H, int W, int kh, int kw, int ph, int 
                         const float* in, const float* in2, const float* weight, const float* bias, float* out,
                         void* stream);
 
+/* One layer of UNet_m.ResBlock, fused (C = 64):
+ *   out = [x (+ x2) +] BN(PReLU(Conv2d(C,C,1)(Conv2d(C,C,(3,3),pad (1,d),dil (1,d),groups=C)(x (+ x2)))))
+ * replacing, per layer, the depthwise conv, the pointwise conv, the shared PReLU, the BatchNorm2d
+ * (eval mode, folded to bn_scale/bn_shift) and the running-value add of UNet_m.py:545-561 -- five tensor
+ * passes -- by one read and one write.  residual = 0 for the block's first layer (r = L0(x)), 1 for
+ * the others (r = r + Li(r)); x2 (or null) is the skip tensor torch.add'ed in front of a decoder's
+ * block (ResUNet.py:209).  dilation_w in {1,2,4,8,16}.  dw_weight [C,1,3,3], pw_weight [C,C,1,1] (torch
+ * layouts), dw_bias / pw_bias [C] or null, prelu_alpha [1], bn_scale / bn_shift [C]; out must not alias
+ * x or x2.  Returns UNETMI_E_UNSUPPORTED for other channel counts (use the unfused entry points). */
+int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const float* x, const float* x2,
+                              const float* dw_weight, const float* dw_bias, const float* pw_weight,
+                              const float* pw_bias, const float* prelu_alpha, const float* bn_scale,
+                              const float* bn_shift, int residual, float* out, void* stream);
+
 /* LayerNorm over the FREQUENCY axis of x[N,C,F,T] (biased variance, affine gamma/beta[F]),
  * written into channels [c_off, c_off+C) of out[N,C_out,F,T].  Replaces
  *   permute -> nn.LayerNorm(257) on [B,C,T,F] -> permute -> torch.cat       ResUNet.py:165-175, :49, :53

@@ -136,3 +136,25 @@ def test_pointwise_kernels(device):
     X1 = X[:, :1].contiguous()
     assert_close(ops.crf_apply(M.to(device), X1.to(device))[:, 0, 0], oracle.crm_apply(X1[:, 0], M[:, 0, 0, 0, 0]),
                  what="complex mask product")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 9, 70), (1, 64, 257, 29), (3, 64, 3, 200), (1, 64, 1, 5)])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_resblock_64_one_launch_per_layer(device, shape, with_add):
+    """The 64-channel block runs the fused layer kernel (depthwise + pointwise + PReLU + BatchNorm +
+    running add in one pass); checked against the oracle on ragged tiles, with and without the skip
+    addend of ResUNet's decoder blocks."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    ref = oracle.ResBlock(64).eval()
+    unet_amd.seeded_fill_(ref, seed=33)
+    dev = unet_amd.ResBlock(64)
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    x = normal("rb64/x", shape, seed=33)
+    add = normal("rb64/add", shape, seed=34) if with_add else None
+    with torch.no_grad():
+        want = ref(x + add) if with_add else ref(x)
+        got = dev(x.to(device), add.to(device)) if with_add else dev(x.to(device))
+    assert_close(got, want, what="ResBlock(64) fused layers")

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import _lib
 from .fused import FusedConv, _pair, require_device_tensor
-from .ops import dwconv2d_fwd
+from .ops import dwconv2d_fwd, resblock_layer
 
 
 def _activation(name, where):
@@ -141,10 +141,11 @@ class ResBlock(nn.Module):
     (UNet_m.py:518-563).  One PReLU instance is shared by the five layers, as in the
     reference, so ``res_{0..4}.2.weight`` alias one tensor.
 
-    Per layer: one depthwise launch (bandwidth-bound) and one fused launch for
-    pointwise conv + bias + PReLU + BatchNorm affine + the running-value add.
-    ``forward(x, add)`` starts from ``x + add`` without forming it (the skip add in
-    front of ResUNet's decoder blocks, ResUNet.py:209)."""
+    With 64 channels (every block of ResUNet) a layer is ONE launch that reads the activation
+    once and writes it once (unetmi_resblock_layer_fwd).  Other widths take two launches per
+    layer: the depthwise conv, then pointwise conv + bias + PReLU + BatchNorm affine + the
+    running-value add.  ``forward(x, add)`` starts from ``x + add`` without forming it (the
+    skip add in front of ResUNet's decoder blocks, ResUNet.py:209)."""
 
     TIME_DILATIONS = (1, 2, 4, 8, 16)
 
@@ -173,6 +174,8 @@ class ResBlock(nn.Module):
             raise NotImplementedError("ResBlock: train-mode forward is not available in this build; call .eval()")
         if self._fused is None:
             object.__setattr__(self, "_fused", [FusedConv(l[1], l[3], l[2], act_first=True) for l in self.layers])
+        if x.shape[1] == 64 and self.layers[0][2].weight.numel() == 1:
+            return self._forward_one_launch_per_layer(x, add)
         r = None
         for i, layer in enumerate(self.layers):
             dw = layer[0]
@@ -180,4 +183,13 @@ class ResBlock(nn.Module):
             t = dwconv2d_fwd(src, add if i == 0 else None, dw.weight, dw.bias, list(_pair(dw.padding)),
                              list(_pair(dw.dilation)))
             r = self._fused[i](t, residual=r)        # layer 0 has no running value to add
+        return r
+
+    def _forward_one_launch_per_layer(self, x, add):
+        r = None
+        for i, layer in enumerate(self.layers):
+            dw, pw = layer[0], layer[1]
+            st = self._fused[i]._prepare(x.device)      # folded BatchNorm scale/shift, PReLU parameter on device
+            r = resblock_layer(x if i == 0 else r, add if i == 0 else None, dw.weight, dw.bias, pw.weight, pw.bias,
+                               st["act_param"], st["scale"], st["shift"], int(_pair(dw.dilation)[1]), i > 0)
         return r

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "unetmi_conv2d_wgrad_workspace_bytes",
     "unetmi_conv2d_wgrad",
     "unetmi_adam_step",
+    "unetmi_resblock_layer_fwd",
 )
 
 
@@ -85,6 +86,8 @@ def _load():
     lib.unetmi_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.unetmi_conv2d_wgrad_workspace_bytes.restype = sz
     lib.unetmi_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 4 + [vp, sz, vp]
+    lib.unetmi_resblock_layer_fwd.argtypes = [ci] * 5 + [fp] * 9 + [ci, fp, vp]
+    lib.unetmi_resblock_layer_fwd.restype = ctypes.c_int
     lib.unetmi_adam_step.argtypes = [sz] + [fp] * 4 + [cf] * 6 + [ci, vp]
     for f in (lib.unetmi_bn_train_stats, lib.unetmi_bn_act_fwd, lib.unetmi_bn_act_bwd, lib.unetmi_conv2d_wgrad,
               lib.unetmi_adam_step):

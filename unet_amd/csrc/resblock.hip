@@ -1,0 +1,268 @@
+// One layer of the residual block, fused:
+//     out = [src +] BN(PReLU(pointwise_1x1(depthwise_3x3_dilated(src))))        src = x [+ x2]
+// (UNet_m.py:545-561: dw Conv2d(C,C,3x3,pad (1,d),dil (1,d),groups=C) -> Conv2d(C,C,1) -> PReLU -> BatchNorm2d,
+//  layer 0 replaces the running value, layers 1..4 add to it), C = 64.
+//
+// The layer is bandwidth-bound (one read and one write of the activation is the floor), so the
+// unfused form -- depthwise pass, pointwise pass, residual read: five tensor passes -- is replaced
+// by one kernel that reads the tile (with its halo) once and writes once.  A workgroup owns a tile
+// of 4 rows x 64 time steps, all 64 channels, and walks the channels in chunks of 16 (8 at time dilations 8 and 16, whose patches are wider):
+//   * the chunk's input patch [chunk][6][64+2d] is fetched with unconditional buffer loads (lanes
+//     outside the image carry an out-of-range offset and read 0 = the zero padding) while the
+//     previous chunk computes, then parked in LDS;
+//   * the depthwise 3x3 runs on the vector ALUs (thread = one time step x 4 channels x 4 rows, so
+//     each patch value is read from LDS once per thread) and leaves its result in LDS as the B
+//     operand [channel][pixel] of the pointwise product;
+//   * the pointwise 64x64 product runs on v_mfma_f32_32x32x2_f32 with the whole weight matrix kept
+//     in LDS in operand order for the life of the workgroup; wave w owns image row w of the tile.
+// Workgroups are persistent over tiles so the weights are staged once.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/unetmi.h"
+
+namespace unetmi {
+
+int api_fail(int code, const std::string& msg);
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kRbC = 64;        // channels
+constexpr int kRbTR = 4;        // tile rows
+constexpr int kRbTC = 64;       // tile columns
+constexpr int kRbBPitch = 288;  // pitch of a channel row of the B operand (256 pixels + 32: the two
+                                // lane halves of an MFMA read land in different banks)
+
+struct ResblockArgs {
+    const float* x;
+    const float* x2;        // optional addend of the input (x + x2)
+    const float* dw_w;      // [64][3][3]
+    const float* dw_b;      // [64] or null
+    const float* pw_w;      // [64 out][64 in]
+    const float* pw_b;      // [64] or null
+    const float* alpha;     // PReLU parameter [1]
+    const float* scale;     // folded BatchNorm [64]
+    const float* shift;
+    float* out;
+    int N, H, W, residual;
+    int tiles_h, tiles_w, ntiles;
+};
+
+__device__ __forceinline__ float rb_load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockArgs a) {
+    constexpr int kRbCK = D >= 8 ? 8 : 16;                // channels per chunk
+    constexpr int TCP = kRbTC + 2 * D;                    // patch columns
+    constexpr int PROWS = kRbTR + 2;                      // patch rows
+    constexpr int PLANE = PROWS * TCP;
+    constexpr int NEL = kRbCK * PLANE;                    // patch elements of a chunk
+    constexpr int NSLOT = (NEL + 255) / 256;
+    constexpr int kOob = (int)0x80000000;
+    extern __shared__ float smem[];
+    float* s_in = smem;                                   // [NSLOT*256] patch of one chunk
+    float* s_b = smem + NSLOT * 256;                      // [16][kRbBPitch] depthwise result = B operand
+    float* s_w = s_b + kRbCK * kRbBPitch;                 // [32 k-steps][2 tiles][64 lanes] A operands
+    float* s_par = s_w + kRbC * kRbC;                     // [3][64] pointwise bias, BatchNorm scale, shift
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = a.H * a.W;
+
+    // pointwise weights in MFMA operand order: A operand of k-step ks, output tile t, lane l is
+    // W[t*32 + (l&31)][2*ks + (l>>5)]; written once, read conflict-free by every wave
+    for (int i = tid; i < kRbC * kRbC; i += 256) {
+        const int l = i & 63, t = (i >> 6) & 1, ks = i >> 7;
+        s_w[i] = a.pw_w[(t * 32 + (l & 31)) * kRbC + 2 * ks + (l >> 5)];
+    }
+    if (tid < kRbC) {
+        s_par[tid] = a.pw_b ? a.pw_b[tid] : 0.f;
+        s_par[kRbC + tid] = a.scale[tid];
+        s_par[2 * kRbC + tid] = a.shift[tid];
+    }
+    const float alpha = a.alpha[0];
+
+    // depthwise work of this thread: column dcol of the tile, a quarter of the chunk's channels
+    const int dcol = tid & 63, dch0 = (tid >> 6) * (kRbCK / 4);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int n = tile / (a.tiles_h * a.tiles_w);
+        const int rem = tile - n * a.tiles_h * a.tiles_w;
+        const int row0 = (rem / a.tiles_w) * kRbTR, col0 = (rem % a.tiles_w) * kRbTC;
+        const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * kRbC * HW), 0,
+                                                           kRbC * HW * 4, 0x00020000);
+        const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>((a.x2 ? a.x2 : a.x) + (size_t)n * kRbC * HW), 0, a.x2 ? kRbC * HW * 4 : 0, 0x00020000);
+
+        // patch element e = slot*256 + tid -> (channel, row, col) -> byte offset within chunk 0
+        int voff[NSLOT];
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const int e = s * 256 + tid;
+            const int ch = e / PLANE, r = (e % PLANE) / TCP, c = e % TCP;
+            const int grow = row0 - 1 + r, gcol = col0 - D + c;
+            const bool ok = e < NEL && (unsigned)grow < (unsigned)a.H && (unsigned)gcol < (unsigned)a.W;
+            voff[s] = ok ? ((ch * a.H + grow) * a.W + gcol) * 4 : kOob;
+        }
+        float stage[NSLOT];
+        auto fetch = [&](int chunk) {
+            const int soff = chunk * kRbCK * HW * 4;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) stage[s] = rb_load(rs0, voff[s], soff);
+            if (a.x2) {
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) stage[s] += rb_load(rs1, voff[s], soff);
+            }
+        };
+        auto park = [&]() {
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) s_in[s * 256 + tid] = stage[s];
+        };
+
+        f32x16 acc[2][2];              // [output-channel tile][pixel tile of this wave's row]
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][h][r] = 0.f;
+
+        fetch(0);
+        park();
+        __syncthreads();
+#pragma nounroll
+        for (int chunk = 0; chunk < kRbC / kRbCK; ++chunk) {
+            if (chunk + 1 < kRbC / kRbCK) fetch(chunk + 1);
+            // ---- depthwise 3x3, dilation (1, D) ----
+#pragma unroll
+            for (int cc = 0; cc < kRbCK / 4; ++cc) {
+                const int chl = dch0 + cc, chg = chunk * kRbCK + chl;
+                float k[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) k[i] = a.dw_w[chg * 9 + i];
+                const float b = a.dw_b ? a.dw_b[chg] : 0.f;
+                float v[PROWS][3];
+#pragma unroll
+                for (int r = 0; r < PROWS; ++r)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) v[r][q] = s_in[chl * PLANE + r * TCP + dcol + q * D];
+#pragma unroll
+                for (int r = 0; r < kRbTR; ++r) {
+                    float o = b;
+#pragma unroll
+                    for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) o = fmaf(v[r + kr][q], k[kr * 3 + q], o);
+                    s_b[chl * kRbBPitch + r * kRbTC + dcol] = o;
+                }
+            }
+            __syncthreads();
+            // ---- pointwise product over this chunk's 16 input channels ----
+#pragma unroll
+            for (int ks = 0; ks < kRbCK / 2; ++ks) {
+                const int gks = chunk * (kRbCK / 2) + ks;
+                float bv[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    bv[h] = s_b[(2 * ks + (lane >> 5)) * kRbBPitch + wave * kRbTC + h * 32 + (lane & 31)];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float av = s_w[(gks * 2 + t) * 64 + lane];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        acc[t][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[h], acc[t][h], 0, 0, 0);
+                }
+            }
+            if (chunk + 1 < kRbC / kRbCK) park();
+            __syncthreads();
+        }
+
+        // ---- epilogue: bias, PReLU, BatchNorm affine, optional residual ----
+        // buffer loads/stores with 32-bit offsets; lanes outside the image carry an out-of-range
+        // offset (stores dropped, loads 0), so there is no branch per element
+        const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)n * kRbC * HW, 0, kRbC * HW * 4, 0x00020000);
+        const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * kRbC * HW), 0,
+                                                              a.residual ? kRbC * HW * 4 : 0, 0x00020000);
+        const int orow = row0 + wave;
+        int obase[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ocol = col0 + h * 32 + (lane & 31);
+            obase[h] = (orow < a.H && ocol < a.W) ? ((4 * (lane >> 5)) * HW + orow * a.W + ocol) * 4 : kOob;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cou = t * 32 + (r & 3) + 8 * (r >> 2);            // + 4*(lane>>5), folded into obase
+                const int co = cou + 4 * (lane >> 5);
+                const float pb = s_par[co], sc = s_par[kRbC + co], sh = s_par[2 * kRbC + co];
+                const int soff = cou * HW * 4;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float v = acc[t][h][r] + pb;
+                    v = v >= 0.f ? v : alpha * v;
+                    v = fmaf(v, sc, sh);
+                    v += rb_load(rs_res, obase[h], soff);
+                    if (a.x2) v += rb_load(rs1, obase[h], soff) * (float)a.residual;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs_out, obase[h], soff, 0);
+                }
+            }
+    }
+}
+
+template <int D>
+static hipError_t launch_resblock(int grid, hipStream_t s, const ResblockArgs& a) {
+    constexpr int kRbCK = D >= 8 ? 8 : 16;
+    constexpr int NSLOT = (kRbCK * (kRbTR + 2) * (kRbTC + 2 * D) + 255) / 256;
+    constexpr size_t lds = (size_t)(NSLOT * 256 + kRbCK * kRbBPitch + kRbC * kRbC + 3 * kRbC) * sizeof(float);
+    static bool raised = false;                     // dynamic LDS beyond 64 KB is requested once per kernel
+    if (!raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_layer_kernel<D>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(resblock_layer_kernel<D>, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace unetmi
+
+using namespace unetmi;
+
+extern "C" int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const float* x, const float* x2,
+                                         const float* dw_weight, const float* dw_bias, const float* pw_weight,
+                                         const float* pw_bias, const float* prelu_alpha, const float* bn_scale,
+                                         const float* bn_shift, int residual, float* out, void* stream) {
+    if (N < 0 || H < 1 || W < 1) return api_fail(UNETMI_E_BAD_DESC, "resblock_layer: bad sizes");
+    if (C != kRbC) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: built for 64 channels");
+    if ((long long)C * H * W * 4 >= (1ll << 31)) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: sample larger than 2 GiB");
+    if (N == 0) return UNETMI_OK;
+    if (!x || !dw_weight || !pw_weight || !prelu_alpha || !bn_scale || !bn_shift || !out)
+        return api_fail(UNETMI_E_BAD_ARG, "resblock_layer: null pointer");
+    if (out == x || (x2 && out == x2)) return api_fail(UNETMI_E_BAD_ARG, "resblock_layer: out must not alias an input");
+    ResblockArgs a{};
+    a.x = x; a.x2 = x2; a.dw_w = dw_weight; a.dw_b = dw_bias; a.pw_w = pw_weight; a.pw_b = pw_bias;
+    a.alpha = prelu_alpha; a.scale = bn_scale; a.shift = bn_shift; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.residual = residual ? 1 : 0;
+    a.tiles_h = (H + kRbTR - 1) / kRbTR; a.tiles_w = (W + kRbTC - 1) / kRbTC;
+    const long long nt = (long long)N * a.tiles_h * a.tiles_w;
+    if (nt > 0x7fffffffll) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: too many tiles");
+    a.ntiles = (int)nt;
+    const int grid = (int)std::min<long long>(nt, 256 * 2 * 4);       // persistent: a few tiles per workgroup
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    switch (dilation_w) {
+        case 1: e = launch_resblock<1>(grid, s, a); break;
+        case 2: e = launch_resblock<2>(grid, s, a); break;
+        case 4: e = launch_resblock<4>(grid, s, a); break;
+        case 8: e = launch_resblock<8>(grid, s, a); break;
+        case 16: e = launch_resblock<16>(grid, s, a); break;
+        default: return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: time dilation must be 1, 2, 4, 8 or 16");
+    }
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("resblock_layer launch: ") + hipGetErrorString(e));
+}

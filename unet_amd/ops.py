@@ -150,6 +150,8 @@ _LIBRARY.define("dwconv2d_fwd(Tensor x, Tensor? x2, Tensor weight, Tensor? bias,
 _LIBRARY.define("layernorm_f(Tensor x, Tensor gamma, Tensor beta, float eps, Tensor(a!) out, int c_off) -> ()")
 _LIBRARY.define("tanh_mask_mul(Tensor y, Tensor x, float eps) -> Tensor")
 _LIBRARY.define("crf_apply(Tensor H, Tensor X) -> Tensor")
+_LIBRARY.define("resblock_layer(Tensor x, Tensor? x2, Tensor dw_weight, Tensor? dw_bias, Tensor pw_weight, "
+                "Tensor? pw_bias, Tensor alpha, Tensor scale, Tensor shift, int dilation, bool residual) -> Tensor")
 
 
 def _dev(t, name, op):
@@ -216,6 +218,27 @@ def _crf_apply_cuda(H, X):
     return Y
 
 
+def _resblock_layer_cuda(x, x2, dw_weight, dw_bias, pw_weight, pw_bias, alpha, scale, shift, dilation, residual):
+    _dev(x, "x", "resblock_layer")
+    N, C, H, W = x.shape
+    for t, name, numel in ((dw_weight, "dw_weight", C * 9), (pw_weight, "pw_weight", C * C), (alpha, "alpha", 1),
+                           (scale, "scale", C), (shift, "shift", C)):
+        _dev(t, name, "resblock_layer")
+        if t.numel() != numel:
+            raise ValueError("unetmi::resblock_layer: {} has {} elements, expected {}".format(name, t.numel(), numel))
+    if x2 is not None:
+        _dev(x2, "x2", "resblock_layer")
+        if x2.shape != x.shape:
+            raise ValueError("unetmi::resblock_layer: x2 shape differs from x")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(_lib.lib.unetmi_resblock_layer_fwd(N, C, H, W, dilation, _ptr(x), _ptr(x2), _ptr(dw_weight), _ptr(dw_bias),
+                                                 _ptr(pw_weight), _ptr(pw_bias), _ptr(alpha), _ptr(scale), _ptr(shift),
+                                                 int(residual), _ptr(out), _stream(x)), "unetmi_resblock_layer_fwd")
+    return out
+
+
+_LIBRARY.impl("resblock_layer", _resblock_layer_cuda, "CUDA")
 _LIBRARY.impl("dwconv2d_fwd", _dwconv2d_fwd_cuda, "CUDA")
 _LIBRARY.impl("layernorm_f", _layernorm_f_cuda, "CUDA")
 _LIBRARY.impl("tanh_mask_mul", _tanh_mask_mul_cuda, "CUDA")
@@ -224,6 +247,11 @@ _LIBRARY.impl("crf_apply", _crf_apply_cuda, "CUDA")
 
 @torch.library.register_fake("unetmi::dwconv2d_fwd")
 def _(x, x2, weight, bias, padding, dilation):
+    return torch.empty_like(x)
+
+
+@torch.library.register_fake("unetmi::resblock_layer")
+def _(x, x2, dw_weight, dw_bias, pw_weight, pw_bias, alpha, scale, shift, dilation, residual):
     return torch.empty_like(x)
 
 
@@ -241,3 +269,4 @@ dwconv2d_fwd = torch.ops.unetmi.dwconv2d_fwd
 layernorm_f = torch.ops.unetmi.layernorm_f
 tanh_mask_mul = torch.ops.unetmi.tanh_mask_mul
 crf_apply = torch.ops.unetmi.crf_apply
+resblock_layer = torch.ops.unetmi.resblock_layer
