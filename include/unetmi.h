@@ -149,11 +149,21 @@ int unetmi_dwconv2d_fwd(int N, int C, int H, int W, int kh, int kw, int ph, int 
  * the others (r = r + Li(r)); x2 (or null) is the skip tensor torch.add'ed in front of a decoder's
  * block (ResUNet.py:209).  dilation_w in {1,2,4,8,16}.  dw_weight [C,1,3,3], pw_weight [C,C,1,1] (torch
  * layouts), dw_bias / pw_bias [C] or null, prelu_alpha [1], bn_scale / bn_shift [C]; out must not alias
- * x or x2.  Returns UNETMI_E_UNSUPPORTED for other channel counts (use the unfused entry points). */
+ * x or x2; x2 and residual are not combined (the reference never does).  Returns UNETMI_E_UNSUPPORTED for other channel counts (use the unfused entry points). */
 int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const float* x, const float* x2,
                               const float* dw_weight, const float* dw_bias, const float* pw_weight,
                               const float* pw_bias, const float* prelu_alpha, const float* bn_scale,
                               const float* bn_shift, int residual, float* out, void* stream);
+
+/* Pointwise (1x1, stride 1) convolution 64 -> 64 channels with the fused epilogue, as one bandwidth-bound
+ * pass: out = epilogue(weight[64,64] . (x (+ x2)) + bias) (+ x when residual).  The epilogue is
+ * act(v * scale + shift) when act_first = 0 (conv -> BN -> act: the 1x1 res_paths of ResUNet,
+ * ResUNet.py:125-132 through UNet_m.py:340-345) or act(v) * scale + shift when act_first = 1; act is
+ * LeakyReLU / single-parameter PReLU with slope leaky_slope[0], or the identity when leaky_slope is null.
+ * Same tensors as unetmi_conv2d_fwd would take for that layer, except weight in torch layout [64,64,1,1]. */
+int unetmi_pwconv64_fwd(int N, int H, int W, const float* x, const float* x2, const float* weight, const float* bias,
+                        const float* scale, const float* shift, const float* leaky_slope, int act_first, int residual,
+                        float* out, void* stream);
 
 /* LayerNorm over the FREQUENCY axis of x[N,C,F,T] (biased variance, affine gamma/beta[F]),
  * written into channels [c_off, c_off+C) of out[N,C_out,F,T].  Replaces

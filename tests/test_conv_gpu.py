@@ -182,3 +182,21 @@ def test_empty_batch_and_bad_input(device):
     assert tuple(out.shape) == (0, 8, 5, 5)
     with pytest.raises(RuntimeError):
         FusedConv(conv)(torch.zeros(1, 5, 5, 5, device=device))
+
+
+@pytest.mark.parametrize("act", ["PReLU", "LeakyReLU"])
+@pytest.mark.parametrize("shape", [(2, 64, 9, 70), (1, 64, 130, 33)])
+def test_pointwise_64_encoder_block(device, act, shape):
+    """Encoder(64, 64, (1,1)) -- ResUNet's res_paths -- takes the one-pass pointwise kernel; checked
+    against the oracle block (conv -> BN -> act order), ragged tiles."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    ref = oracle.Encoder(64, 64, (1, 1), (1, 1), activation=act).eval()
+    unet_amd.seeded_fill_(ref, seed=61)
+    dev = unet_amd.Encoder(64, 64, (1, 1), (1, 1), activation=act)
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    x = normal("pw64/x", shape, seed=61)
+    with torch.no_grad():
+        assert_close(dev(x.to(device)), ref(x), what="pointwise 64->64 block")

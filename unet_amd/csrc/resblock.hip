@@ -6,7 +6,7 @@
 // The layer is bandwidth-bound (one read and one write of the activation is the floor), so the
 // unfused form -- depthwise pass, pointwise pass, residual read: five tensor passes -- is replaced
 // by one kernel that reads the tile (with its halo) once and writes once.  A workgroup owns a tile
-// of 4 rows x 64 time steps, all 64 channels, and walks the channels in chunks of 16 (8 at time dilations 8 and 16, whose patches are wider):
+// of 4 rows x 64 time steps, all 64 channels, and walks the channels in chunks of 8:
 //   * the chunk's input patch [chunk][6][64+2d] is fetched with unconditional buffer loads (lanes
 //     outside the image carry an out-of-range offset and read 0 = the zero padding) while the
 //     previous chunk computes, then parked in LDS;
@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <string>
+#include <type_traits>
 
 #include "../../include/unetmi.h"
 
@@ -46,7 +47,7 @@ struct ResblockArgs {
     const float* scale;     // folded BatchNorm [64]
     const float* shift;
     float* out;
-    int N, H, W, residual;
+    int N, H, W, residual, act_first;
     int tiles_h, tiles_w, ntiles;
 };
 
@@ -54,22 +55,26 @@ __device__ __forceinline__ float rb_load(__amdgpu_buffer_rsrc_t rs, int voff, in
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
 
-template <int D>
+// DWISE = false drops the depthwise stage: a plain 64 -> 64 pointwise convolution (D = 0, no halo),
+// whose input chunk is parked straight into the B-operand layout.
+template <int D, bool DWISE>
 __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockArgs a) {
-    constexpr int kRbCK = D >= 8 ? 8 : 16;                // channels per chunk
+    constexpr int kRbCK = DWISE ? 8 : 16;                 // channels per chunk
+    constexpr int NCH = kRbC / kRbCK;
     constexpr int TCP = kRbTC + 2 * D;                    // patch columns
-    constexpr int PROWS = kRbTR + 2;                      // patch rows
+    constexpr int PROWS = kRbTR + (DWISE ? 2 : 0);        // patch rows
     constexpr int PLANE = PROWS * TCP;
     constexpr int NEL = kRbCK * PLANE;                    // patch elements of a chunk
     constexpr int NSLOT = (NEL + 255) / 256;
     constexpr int kOob = (int)0x80000000;
     extern __shared__ float smem[];
-    float* s_in = smem;                                   // [NSLOT*256] patch of one chunk
-    float* s_b = smem + NSLOT * 256;                      // [16][kRbBPitch] depthwise result = B operand
+    float* s_in = smem;                                   // [NSLOT*256] patch of one chunk (DWISE only)
+    float* s_b = smem + (DWISE ? NSLOT * 256 : 0);        // [chunk][kRbBPitch] B operand of the pointwise product
     float* s_w = s_b + kRbCK * kRbBPitch;                 // [32 k-steps][2 tiles][64 lanes] A operands
     float* s_par = s_w + kRbC * kRbC;                     // [3][64] pointwise bias, BatchNorm scale, shift
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: lets per-channel constants be scalar loads
     const int HW = a.H * a.W;
 
     // pointwise weights in MFMA operand order: A operand of k-step ks, output tile t, lane l is
@@ -83,44 +88,58 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
         s_par[kRbC + tid] = a.scale[tid];
         s_par[2 * kRbC + tid] = a.shift[tid];
     }
-    const float alpha = a.alpha[0];
+    const float alpha = a.alpha ? a.alpha[0] : 1.f;
 
     // depthwise work of this thread: column dcol of the tile, a quarter of the chunk's channels
-    const int dcol = tid & 63, dch0 = (tid >> 6) * (kRbCK / 4);
+    const int dcol = tid & 63, dch0 = wave * (kRbCK / 4);
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int n = tile / (a.tiles_h * a.tiles_w);
+    int voff[NSLOT];
+    float stage[NSLOT];
+    // patch element e = slot*256 + tid -> (channel, row, col) -> byte offset within chunk 0 of sample n
+    auto aim = [&](int tile, int& n, int& row0, int& col0) {
+        n = tile / (a.tiles_h * a.tiles_w);
         const int rem = tile - n * a.tiles_h * a.tiles_w;
-        const int row0 = (rem / a.tiles_w) * kRbTR, col0 = (rem % a.tiles_w) * kRbTC;
-        const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * kRbC * HW), 0,
-                                                           kRbC * HW * 4, 0x00020000);
-        const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>((a.x2 ? a.x2 : a.x) + (size_t)n * kRbC * HW), 0, a.x2 ? kRbC * HW * 4 : 0, 0x00020000);
-
-        // patch element e = slot*256 + tid -> (channel, row, col) -> byte offset within chunk 0
-        int voff[NSLOT];
+        row0 = (rem / a.tiles_w) * kRbTR;
+        col0 = (rem % a.tiles_w) * kRbTC;
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             const int e = s * 256 + tid;
             const int ch = e / PLANE, r = (e % PLANE) / TCP, c = e % TCP;
-            const int grow = row0 - 1 + r, gcol = col0 - D + c;
+            const int grow = row0 - (DWISE ? 1 : 0) + r, gcol = col0 - D + c;
             const bool ok = e < NEL && (unsigned)grow < (unsigned)a.H && (unsigned)gcol < (unsigned)a.W;
             voff[s] = ok ? ((ch * a.H + grow) * a.W + gcol) * 4 : kOob;
         }
-        float stage[NSLOT];
-        auto fetch = [&](int chunk) {
-            const int soff = chunk * kRbCK * HW * 4;
+    };
+    auto fetch = [&](int n, int chunk) {
+        const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * kRbC * HW), 0,
+                                                           kRbC * HW * 4, 0x00020000);
+        const int soff = chunk * kRbCK * HW * 4;
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s) stage[s] = rb_load(rs0, voff[s], soff);
-            if (a.x2) {
+        for (int s = 0; s < NSLOT; ++s) stage[s] = rb_load(rs0, voff[s], soff);
+        if (a.x2) {
+            const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x2 + (size_t)n * kRbC * HW), 0,
+                                                               kRbC * HW * 4, 0x00020000);
 #pragma unroll
-                for (int s = 0; s < NSLOT; ++s) stage[s] += rb_load(rs1, voff[s], soff);
-            }
-        };
-        auto park = [&]() {
+            for (int s = 0; s < NSLOT; ++s) stage[s] += rb_load(rs1, voff[s], soff);
+        }
+    };
+    auto park = [&]() {
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s) s_in[s * 256 + tid] = stage[s];
-        };
+        for (int s = 0; s < NSLOT; ++s) {
+            const int e = s * 256 + tid;
+            if (DWISE) s_in[e] = stage[s];
+            else s_b[(e >> 8) * kRbBPitch + (e & 255)] = stage[s];      // PLANE = 256: [channel][pixel]
+        }
+    };
+
+    int tile = blockIdx.x, n = 0, row0 = 0, col0 = 0;
+    if (tile < a.ntiles) {
+        aim(tile, n, row0, col0);
+        fetch(n, 0);
+    }
+    while (tile < a.ntiles) {
+        park();
+        __syncthreads();
 
         f32x16 acc[2][2];              // [output-channel tile][pixel tile of this wave's row]
 #pragma unroll
@@ -130,37 +149,63 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][h][r] = 0.f;
 
-        fetch(0);
-        park();
-        __syncthreads();
+        // residual values of this wave's outputs, fetched while the last chunk computes
+        const int orow = row0 + wave;
+        int obase[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ocol = col0 + h * 32 + (lane & 31);
+            obase[h] = (orow < a.H && ocol < a.W) ? ((4 * (lane >> 5)) * HW + orow * a.W + ocol) * 4 : kOob;
+        }
+        float res[2][2][16];
+        auto fetch_residual = [&]() {
+            const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * kRbC * HW), 0,
+                                                                  a.residual ? kRbC * HW * 4 : 0, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int soff = (t * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4;
+                        res[t][h][r] = rb_load(rs_res, obase[h], soff);
+                    }
+        };
+
+        // one chunk: start the next fetch (or, on the last chunk, the residual loads), depthwise stage,
+        // pointwise MFMAs, park what was fetched.  The last chunk is peeled so that the residual
+        // registers and the staging registers are never live together.
+        auto do_chunk = [&](int chunk, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            if (!LAST) fetch(n, chunk + 1);
+            else fetch_residual();
+            if (DWISE) {
+                // ---- depthwise 3x3, dilation (1, D) ---- (one channel at a time: keeps the live set small)
 #pragma nounroll
-        for (int chunk = 0; chunk < kRbC / kRbCK; ++chunk) {
-            if (chunk + 1 < kRbC / kRbCK) fetch(chunk + 1);
-            // ---- depthwise 3x3, dilation (1, D) ----
+                for (int cc = 0; cc < kRbCK / 4; ++cc) {
+                    const int chl = dch0 + cc, chg = chunk * kRbCK + chl;
+                    float k[9];
 #pragma unroll
-            for (int cc = 0; cc < kRbCK / 4; ++cc) {
-                const int chl = dch0 + cc, chg = chunk * kRbCK + chl;
-                float k[9];
+                    for (int i = 0; i < 9; ++i) k[i] = a.dw_w[chg * 9 + i];
+                    const float b = a.dw_b ? a.dw_b[chg] : 0.f;
+                    float v[PROWS][3];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) k[i] = a.dw_w[chg * 9 + i];
-                const float b = a.dw_b ? a.dw_b[chg] : 0.f;
-                float v[PROWS][3];
+                    for (int r = 0; r < PROWS; ++r)
 #pragma unroll
-                for (int r = 0; r < PROWS; ++r)
+                        for (int q = 0; q < 3; ++q) v[r][q] = s_in[chl * PLANE + r * TCP + dcol + q * D];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) v[r][q] = s_in[chl * PLANE + r * TCP + dcol + q * D];
+                    for (int r = 0; r < kRbTR; ++r) {
+                        float o = b;
 #pragma unroll
-                for (int r = 0; r < kRbTR; ++r) {
-                    float o = b;
+                        for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
-                    for (int kr = 0; kr < 3; ++kr)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) o = fmaf(v[r + kr][q], k[kr * 3 + q], o);
-                    s_b[chl * kRbBPitch + r * kRbTC + dcol] = o;
+                            for (int q = 0; q < 3; ++q) o = fmaf(v[r + kr][q], k[kr * 3 + q], o);
+                        s_b[chl * kRbBPitch + r * kRbTC + dcol] = o;
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
-            // ---- pointwise product over this chunk's 16 input channels ----
+            // ---- pointwise product over this chunk's input channels ----
 #pragma unroll
             for (int ks = 0; ks < kRbCK / 2; ++ks) {
                 const int gks = chunk * (kRbCK / 2) + ks;
@@ -176,68 +221,81 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
                         acc[t][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[h], acc[t][h], 0, 0, 0);
                 }
             }
-            if (chunk + 1 < kRbC / kRbCK) park();
+            if (!DWISE) __syncthreads();                  // everyone is done reading s_b before it is refilled
+            if (!LAST) park();
             __syncthreads();
-        }
+        };
+#pragma nounroll
+        for (int chunk = 0; chunk < NCH - 1; ++chunk) do_chunk(chunk, std::false_type{});
+        do_chunk(NCH - 1, std::true_type{});
 
-        // ---- epilogue: bias, PReLU, BatchNorm affine, optional residual ----
-        // buffer loads/stores with 32-bit offsets; lanes outside the image carry an out-of-range
-        // offset (stores dropped, loads 0), so there is no branch per element
-        const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)n * kRbC * HW, 0, kRbC * HW * 4, 0x00020000);
-        const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * kRbC * HW), 0,
-                                                              a.residual ? kRbC * HW * 4 : 0, 0x00020000);
-        const int orow = row0 + wave;
-        int obase[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ocol = col0 + h * 32 + (lane & 31);
-            obase[h] = (orow < a.H && ocol < a.W) ? ((4 * (lane >> 5)) * HW + orow * a.W + ocol) * 4 : kOob;
-        }
+        const int cur_n = n;
+        const int next = tile + gridDim.x;
+
+        // ---- epilogue: bias, PReLU and BatchNorm affine in the layer's order, optional residual ----
+        // buffer stores with 32-bit offsets; lanes outside the image carry an out-of-range offset
+        const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)cur_n * kRbC * HW, 0, kRbC * HW * 4, 0x00020000);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cou = t * 32 + (r & 3) + 8 * (r >> 2);            // + 4*(lane>>5), folded into obase
-                const int co = cou + 4 * (lane >> 5);
-                const float pb = s_par[co], sc = s_par[kRbC + co], sh = s_par[2 * kRbC + co];
-                const int soff = cou * HW * 4;
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float v = acc[t][h][r] + pb;
-                    v = v >= 0.f ? v : alpha * v;
-                    v = fmaf(v, sc, sh);
-                    v += rb_load(rs_res, obase[h], soff);
-                    if (a.x2) v += rb_load(rs1, obase[h], soff) * (float)a.residual;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs_out, obase[h], soff, 0);
+                for (int r = 0; r < 16; ++r) {
+                    const int cou = t * 32 + (r & 3) + 8 * (r >> 2);            // + 4*(lane>>5), folded into obase
+                    const int co = cou + 4 * (lane >> 5);
+                    float v = acc[t][h][r] + s_par[co];
+                    if (a.act_first) {
+                        v = v >= 0.f ? v : alpha * v;
+                        v = fmaf(v, s_par[kRbC + co], s_par[2 * kRbC + co]);
+                    } else {
+                        v = fmaf(v, s_par[kRbC + co], s_par[2 * kRbC + co]);
+                        v = v >= 0.f ? v : alpha * v;
+                    }
+                    v += res[t][h][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs_out, obase[h], cou * HW * 4, 0);
                 }
-            }
+        if (next < a.ntiles) {
+            aim(next, n, row0, col0);
+            fetch(n, 0);
+        }
+        tile = next;
     }
 }
 
-template <int D>
+template <int D, bool DWISE>
 static hipError_t launch_resblock(int grid, hipStream_t s, const ResblockArgs& a) {
-    constexpr int kRbCK = D >= 8 ? 8 : 16;
-    constexpr int NSLOT = (kRbCK * (kRbTR + 2) * (kRbTC + 2 * D) + 255) / 256;
-    constexpr size_t lds = (size_t)(NSLOT * 256 + kRbCK * kRbBPitch + kRbC * kRbC + 3 * kRbC) * sizeof(float);
+    constexpr int kRbCK = DWISE ? 8 : 16;
+    constexpr int NSLOT = (kRbCK * (kRbTR + (DWISE ? 2 : 0)) * (kRbTC + 2 * D) + 255) / 256;
+    constexpr size_t lds = (size_t)((DWISE ? NSLOT * 256 : 0) + kRbCK * kRbBPitch + kRbC * kRbC + 3 * kRbC) * sizeof(float);
     static bool raised = false;                     // dynamic LDS beyond 64 KB is requested once per kernel
     if (!raised) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_layer_kernel<D>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_layer_kernel<D, DWISE>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL(resblock_layer_kernel<D>, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((resblock_layer_kernel<D, DWISE>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
+}
+
+static int fill_tiles(ResblockArgs& a) {
+    a.tiles_h = (a.H + kRbTR - 1) / kRbTR; a.tiles_w = (a.W + kRbTC - 1) / kRbTC;
+    const long long nt = (long long)a.N * a.tiles_h * a.tiles_w;
+    if (nt > 0x7fffffffll) return -1;
+    a.ntiles = (int)nt;
+    return (int)std::min<long long>(nt, 256 * 2 * 4);       // persistent: a few tiles per workgroup
 }
 
 }  // namespace unetmi
 
 using namespace unetmi;
 
-extern "C" int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const float* x, const float* x2,
-                                         const float* dw_weight, const float* dw_bias, const float* pw_weight,
-                                         const float* pw_bias, const float* prelu_alpha, const float* bn_scale,
-                                         const float* bn_shift, int residual, float* out, void* stream) {
+extern "C" {
+
+int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const float* x, const float* x2,
+                              const float* dw_weight, const float* dw_bias, const float* pw_weight,
+                              const float* pw_bias, const float* prelu_alpha, const float* bn_scale,
+                              const float* bn_shift, int residual, float* out, void* stream) {
     if (N < 0 || H < 1 || W < 1) return api_fail(UNETMI_E_BAD_DESC, "resblock_layer: bad sizes");
     if (C != kRbC) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: built for 64 channels");
     if ((long long)C * H * W * 4 >= (1ll << 31)) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: sample larger than 2 GiB");
@@ -245,24 +303,42 @@ extern "C" int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilatio
     if (!x || !dw_weight || !pw_weight || !prelu_alpha || !bn_scale || !bn_shift || !out)
         return api_fail(UNETMI_E_BAD_ARG, "resblock_layer: null pointer");
     if (out == x || (x2 && out == x2)) return api_fail(UNETMI_E_BAD_ARG, "resblock_layer: out must not alias an input");
+    if (x2 && residual) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: an input addend together with the residual add is not built");
     ResblockArgs a{};
     a.x = x; a.x2 = x2; a.dw_w = dw_weight; a.dw_b = dw_bias; a.pw_w = pw_weight; a.pw_b = pw_bias;
     a.alpha = prelu_alpha; a.scale = bn_scale; a.shift = bn_shift; a.out = out;
-    a.N = N; a.H = H; a.W = W; a.residual = residual ? 1 : 0;
-    a.tiles_h = (H + kRbTR - 1) / kRbTR; a.tiles_w = (W + kRbTC - 1) / kRbTC;
-    const long long nt = (long long)N * a.tiles_h * a.tiles_w;
-    if (nt > 0x7fffffffll) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: too many tiles");
-    a.ntiles = (int)nt;
-    const int grid = (int)std::min<long long>(nt, 256 * 2 * 4);       // persistent: a few tiles per workgroup
+    a.N = N; a.H = H; a.W = W; a.residual = residual ? 1 : 0; a.act_first = 1;
+    const int grid = fill_tiles(a);
+    if (grid < 0) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: too many tiles");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e;
     switch (dilation_w) {
-        case 1: e = launch_resblock<1>(grid, s, a); break;
-        case 2: e = launch_resblock<2>(grid, s, a); break;
-        case 4: e = launch_resblock<4>(grid, s, a); break;
-        case 8: e = launch_resblock<8>(grid, s, a); break;
-        case 16: e = launch_resblock<16>(grid, s, a); break;
+        case 1: e = launch_resblock<1, true>(grid, s, a); break;
+        case 2: e = launch_resblock<2, true>(grid, s, a); break;
+        case 4: e = launch_resblock<4, true>(grid, s, a); break;
+        case 8: e = launch_resblock<8, true>(grid, s, a); break;
+        case 16: e = launch_resblock<16, true>(grid, s, a); break;
         default: return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: time dilation must be 1, 2, 4, 8 or 16");
     }
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("resblock_layer launch: ") + hipGetErrorString(e));
 }
+
+int unetmi_pwconv64_fwd(int N, int H, int W, const float* x, const float* x2, const float* weight, const float* bias,
+                        const float* scale, const float* shift, const float* leaky_slope, int act_first, int residual,
+                        float* out, void* stream) {
+    if (N < 0 || H < 1 || W < 1) return api_fail(UNETMI_E_BAD_DESC, "pwconv64: bad sizes");
+    if ((long long)kRbC * H * W * 4 >= (1ll << 31)) return api_fail(UNETMI_E_UNSUPPORTED, "pwconv64: sample larger than 2 GiB");
+    if (N == 0) return UNETMI_OK;
+    if (!x || !weight || !scale || !shift || !out) return api_fail(UNETMI_E_BAD_ARG, "pwconv64: null pointer");
+    if (out == x || (x2 && out == x2)) return api_fail(UNETMI_E_BAD_ARG, "pwconv64: out must not alias an input");
+    if (x2 && residual) return api_fail(UNETMI_E_UNSUPPORTED, "pwconv64: an input addend together with the residual add is not built");
+    ResblockArgs a{};
+    a.x = x; a.x2 = x2; a.pw_w = weight; a.pw_b = bias; a.alpha = leaky_slope; a.scale = scale; a.shift = shift;
+    a.out = out; a.N = N; a.H = H; a.W = W; a.residual = residual ? 1 : 0; a.act_first = act_first ? 1 : 0;
+    const int grid = fill_tiles(a);
+    if (grid < 0) return api_fail(UNETMI_E_UNSUPPORTED, "pwconv64: too many tiles");
+    const hipError_t e = launch_resblock<0, false>(grid, static_cast<hipStream_t>(stream), a);
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("pwconv64 launch: ") + hipGetErrorString(e));
+}
+
+}  // extern "C"

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .ops import conv2d_fwd, pack_conv_weights
+from .ops import conv2d_fwd, pack_conv_weights, pwconv64
 
 
 def _pair(v):
@@ -149,6 +149,14 @@ class FusedConv:
         self._key = key
         return self._state
 
+    def _is_pointwise_64(self, st, mode):
+        c = self.conv
+        if st["transposed"] or c.in_channels != 64 or c.out_channels != 64 or mode == _lib.IN_CONCAT:
+            return False
+        if st["geom"][1:9] != [1, 1, 1, 1, 0, 0, 1, 1] or st["act"] not in (_lib.ACT_NONE, _lib.ACT_LEAKY):
+            return False
+        return st["act_param"] is None or st["act_param"].numel() == 1
+
     def _image(self, st, C0, C1, mode):
         """Packed weights for this call: a concatenated input is chunked per source inside the
         kernel, so its image depends on where the channels split (cached per split)."""
@@ -174,6 +182,11 @@ class FusedConv:
         cin = x.shape[1] + (x2.shape[1] if (x2 is not None and mode == _lib.IN_CONCAT) else 0)
         if cin != self.conv.in_channels:
             raise RuntimeError("expected {} input channels, got {}".format(self.conv.in_channels, cin))
+        if epilogue and residual is None and gate is None and self._is_pointwise_64(st, mode):
+            # 64 -> 64 pointwise layer: the bandwidth-bound one-pass kernel
+            slope = st["act_param"] if st["act"] == _lib.ACT_LEAKY else None
+            return pwconv64(x, x2, self._weight_for_split, st["bias"], st["scale"], st["shift"], slope,
+                            self.act_first, False)
         wimg = self._image(st, x.shape[1], x2.shape[1] if x2 is not None else 0, mode)
         if epilogue:
             try:

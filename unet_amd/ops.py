@@ -150,6 +150,8 @@ _LIBRARY.define("dwconv2d_fwd(Tensor x, Tensor? x2, Tensor weight, Tensor? bias,
 _LIBRARY.define("layernorm_f(Tensor x, Tensor gamma, Tensor beta, float eps, Tensor(a!) out, int c_off) -> ()")
 _LIBRARY.define("tanh_mask_mul(Tensor y, Tensor x, float eps) -> Tensor")
 _LIBRARY.define("crf_apply(Tensor H, Tensor X) -> Tensor")
+_LIBRARY.define("pwconv64(Tensor x, Tensor? x2, Tensor weight, Tensor? bias, Tensor scale, Tensor shift, Tensor? slope, "
+                "bool act_first, bool residual) -> Tensor")
 _LIBRARY.define("resblock_layer(Tensor x, Tensor? x2, Tensor dw_weight, Tensor? dw_bias, Tensor pw_weight, "
                 "Tensor? pw_bias, Tensor alpha, Tensor scale, Tensor shift, int dilation, bool residual) -> Tensor")
 
@@ -238,7 +240,27 @@ def _resblock_layer_cuda(x, x2, dw_weight, dw_bias, pw_weight, pw_bias, alpha, s
     return out
 
 
+def _pwconv64_cuda(x, x2, weight, bias, scale, shift, slope, act_first, residual):
+    _dev(x, "x", "pwconv64")
+    N, C, H, W = x.shape
+    if C != 64 or weight.numel() != 64 * 64:
+        raise ValueError("unetmi::pwconv64: built for 64 -> 64 channels")
+    for t, name in ((weight, "weight"), (scale, "scale"), (shift, "shift")):
+        _dev(t, name, "pwconv64")
+    if x2 is not None:
+        _dev(x2, "x2", "pwconv64")
+        if x2.shape != x.shape:
+            raise ValueError("unetmi::pwconv64: x2 shape differs from x")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(_lib.lib.unetmi_pwconv64_fwd(N, H, W, _ptr(x), _ptr(x2), _ptr(weight), _ptr(bias), _ptr(scale), _ptr(shift),
+                                           _ptr(slope), int(act_first), int(residual), _ptr(out), _stream(x)),
+              "unetmi_pwconv64_fwd")
+    return out
+
+
 _LIBRARY.impl("resblock_layer", _resblock_layer_cuda, "CUDA")
+_LIBRARY.impl("pwconv64", _pwconv64_cuda, "CUDA")
 _LIBRARY.impl("dwconv2d_fwd", _dwconv2d_fwd_cuda, "CUDA")
 _LIBRARY.impl("layernorm_f", _layernorm_f_cuda, "CUDA")
 _LIBRARY.impl("tanh_mask_mul", _tanh_mask_mul_cuda, "CUDA")
@@ -247,6 +269,11 @@ _LIBRARY.impl("crf_apply", _crf_apply_cuda, "CUDA")
 
 @torch.library.register_fake("unetmi::dwconv2d_fwd")
 def _(x, x2, weight, bias, padding, dilation):
+    return torch.empty_like(x)
+
+
+@torch.library.register_fake("unetmi::pwconv64")
+def _(x, x2, weight, bias, scale, shift, slope, act_first, residual):
     return torch.empty_like(x)
 
 
@@ -270,3 +297,4 @@ layernorm_f = torch.ops.unetmi.layernorm_f
 tanh_mask_mul = torch.ops.unetmi.tanh_mask_mul
 crf_apply = torch.ops.unetmi.crf_apply
 resblock_layer = torch.ops.unetmi.resblock_layer
+pwconv64 = torch.ops.unetmi.pwconv64
