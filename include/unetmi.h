@@ -165,6 +165,19 @@ int unetmi_pwconv64_fwd(int N, int H, int W, const float* x, const float* x2, co
                         const float* scale, const float* shift, const float* leaky_slope, int act_first, int residual,
                         float* out, void* stream);
 
+/* Time recurrence of one layer of a projected LSTM (nn.LSTM(..., hidden 640, proj_size P), the bottleneck of
+ * ResUNet.py:139,186-197) as one persistent launch.  The caller does the time-parallel parts as GEMMs:
+ *   gx[t][g*H+u][b]  = (W_ih x_t + b_ih + b_hh)[g*H+u]  for all t     (gate order i, f, g, o)
+ *   wrec[4H][H]      = W_hh W_hr                                       (recurrent and projection matrix folded)
+ * and reads the pre-projection states back:  hfull[t+1][u][b] = o_t * tanh(c_t);  h_t = W_hr hfull[t+1].
+ * hfull is [T+1][H][BP] with slot 0 = the initial state (zeros for the reference's call); BP = batch padded to
+ * a multiple of 16 (<= 64; padded columns compute on zeros and are ignored).  sync_ws: 8 bytes of device
+ * scratch (cleared by the call).  H must be 640.  All workgroups have to be resident at once (H/4 <= number of
+ * compute units); the call refuses otherwise.  If the device-wide barrier inside ever times out the last slot
+ * of hfull is filled with NaN. */
+int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, void* sync_ws,
+                           void* stream);
+
 /* LayerNorm over the FREQUENCY axis of x[N,C,F,T] (biased variance, affine gamma/beta[F]),
  * written into channels [c_off, c_off+C) of out[N,C_out,F,T].  Replaces
  *   permute -> nn.LayerNorm(257) on [B,C,T,F] -> permute -> torch.cat       ResUNet.py:165-175, :49, :53

@@ -158,3 +158,25 @@ def test_resblock_64_one_launch_per_layer(device, shape, with_add):
         want = ref(x + add) if with_add else ref(x)
         got = dev(x.to(device), add.to(device)) if with_add else dev(x.to(device))
     assert_close(got, want, what="ResBlock(64) fused layers")
+
+
+@pytest.mark.parametrize("B,T", [(1, 16), (5, 37), (32, 12)])
+def test_projected_lstm_matches_torch_cpu(device, B, T):
+    """ResUNet's bottleneck LSTM(384, 640, 3, proj_size=384) through the persistent recurrence kernel
+    against torch's CPU LSTM (the arithmetic the reference uses)."""
+    import unet_amd
+    from unet_amd.lstm import lstm_forward, supported
+    from unet_amd.seeding import normal
+    ref = torch.nn.LSTM(384, 640, 3, batch_first=True, proj_size=384)
+    holder = torch.nn.Module()
+    holder.lstm = ref
+    unet_amd.seeded_fill_(holder, seed=71)
+    assert supported(ref)
+    x = normal("lstm/x", (B, T, 384), seed=71)
+    with torch.no_grad():
+        want = ref(x)[0]
+    import copy
+    dev = copy.deepcopy(ref).to(device)
+    got = lstm_forward(dev, x.to(device), {})
+    assert not torch.isnan(got).any(), "the recurrence kernel aborted"
+    assert_close(got, want, tol=2e-5, what="projected LSTM")

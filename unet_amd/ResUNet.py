@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .UNet_m import Decoder, Encoder, ResBlock
 from .fused import FusedConv, require_device_tensor
+from .lstm import lstm_forward, supported as lstm_supported
 from .ops import layernorm_f, tanh_mask_mul
 
 
@@ -58,6 +59,7 @@ class ResUNet(nn.Module):
         self.out_layer = nn.ConvTranspose2d(C, 2, (3, 1), stride=1, padding=(1, 0), dilation=1, output_padding=(0, 0))
         self.last_activation = nn.Tanh()
         self._in_data = self._in_af = self._out = None
+        self._lstm_cache = {}
 
     def _input_branch(self, branch, cache_name, x, out, c_off):
         fused = getattr(self, cache_name)
@@ -84,9 +86,13 @@ class ResUNet(nn.Module):
                 print("x_{} : {}".format(i, x.shape))
             res.append(x)
 
-        # [B,C,1,T] -> [B,T,C] -> projected LSTM (torch's device implementation) -> [B,C,1,T]
+        # [B,C,1,T] -> [B,T,C] -> projected LSTM -> [B,C,1,T]: one persistent launch per layer for the
+        # recurrence (unet_amd/lstm.py); an LSTM of another shape runs torch's device implementation
         seq = x.reshape(x.shape[0], x.shape[1], x.shape[3]).permute(0, 2, 1)
-        seq = self.bottleneck(seq)[0]
+        if lstm_supported(self.bottleneck):
+            seq = lstm_forward(self.bottleneck, seq, self._lstm_cache)
+        else:
+            seq = self.bottleneck(seq)[0]
         y = seq.permute(0, 2, 1).reshape(x.shape[0], x.shape[1], 1, x.shape[3]).contiguous()
 
         for i, rp in enumerate(self.res_paths):

@@ -1,0 +1,165 @@
+// Recurrent part of the projected LSTM bottleneck (nn.LSTM(384, 640, 3, proj_size=384), ResUNet.py:139),
+// as ONE persistent kernel per layer instead of three launches per time step.
+//
+// With a projection the recurrence is  gates_t = Gx_t + W_hh (W_hr hfull_{t-1})  where hfull = o * tanh(c) is
+// the 640-wide pre-projection state.  The host folds the two matrices, Wrec = W_hh W_hr [4H x H], so a step
+// needs a single product and a single exchange, and does everything that has no time dependency as large
+// library GEMMs outside this kernel (Gx = W_ih x + b for all t before, h = W_hr hfull for all t after).
+//
+// Workgroup j owns hidden units 4j..4j+3: its 16 rows of Wrec (4 gates x 4 units) stay in LDS in MFMA
+// operand order for all T steps, its cell state stays in registers.  Per step each of its 4 waves multiplies
+// a quarter of the K range with v_mfma_f32_16x16x4_f32 (B operand = hfull_{t-1}, read straight from L2 into
+// registers), the partial sums meet in LDS, 4 x batch threads apply the gate nonlinearities and write the
+// new hfull rows, and the H/4 workgroups meet at a device-wide barrier (one atomic counter, release /
+// acquire fences).  The barrier spin is bounded: after the limit a workgroup raises an abort flag that
+// releases every other workgroup, and the output is poisoned with NaN, so the grid always drains.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <string>
+
+#include "../../include/unetmi.h"
+
+namespace unetmi {
+
+int api_fail(int code, const std::string& msg);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLstmH = 640;              // hidden size the kernel is built for
+constexpr int kLstmKS = kLstmH / 16;     // 16x16x4 k-steps per wave (K split over 4 waves)
+constexpr unsigned kSpinLimit = 1u << 22;
+
+struct LstmArgs {
+    const float* wrec;     // [4H][H] folded recurrent matrix, row g*H + u
+    const float* gx;       // [T][4H][BP] input contribution incl. both biases
+    float* hfull;          // [T+1][H][BP]; slot 0 = initial state, step t reads slot t and writes slot t+1
+    unsigned* sync;        // [0] arrival counter, [1] abort flag
+    int T, BP, nwg;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// Device-wide barrier over the nwg co-resident workgroups.  Returns false when aborted.
+__device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, int* s_flag) {
+    __threadfence();                       // release: this thread's hfull stores become visible device-wide
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sync[0], 1u);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++spins > kSpinLimit) {
+                atomicExch(&sync[1], 1u);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *s_flag = ok;
+    }
+    __syncthreads();
+    __threadfence();                       // acquire: later loads observe the other workgroups' stores
+    return *s_flag != 0;
+}
+
+template <int NCT>      // 16-column batch tiles: BP = 16 * NCT
+__global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs a) {
+    constexpr int BP = 16 * NCT;
+    __shared__ float s_a[kLstmH / 4 * 64];            // [k-step][lane] A operands: 16 rows x 640
+    __shared__ float s_p[4][16][BP + 1];              // per-wave partial gate sums
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u0 = blockIdx.x * 4;
+
+    // A operand of k-step ks, lane l: Wrec[row(l&15)][4*ks + (l>>4)], row r = gate (r>>2), unit u0 + (r&3)
+    for (int i = tid; i < kLstmH / 4 * 64; i += 256) {
+        const int l = i & 63, ks = i >> 6, r = l & 15;
+        s_a[i] = a.wrec[(size_t)((r >> 2) * kLstmH + u0 + (r & 3)) * kLstmH + 4 * ks + (l >> 4)];
+    }
+    // cell-update thread: unit u0 + cu, batch column cb
+    const int cu = tid / BP, cb = tid - cu * BP;
+    const bool cell_thread = tid < 4 * BP;
+    float c = 0.f;
+    __syncthreads();
+
+    bool alive = true;
+    for (int t = 0; t < a.T && alive; ++t) {
+        const float* hprev = a.hfull + (size_t)t * kLstmH * BP;
+        // ---- this wave's quarter of the K range ----
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float bv[kLstmKS][NCT];
+#pragma unroll
+        for (int ks = 0; ks < kLstmKS; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                bv[ks][ct] = hprev[(size_t)(4 * (wave * kLstmKS + ks) + (lane >> 4)) * BP + ct * 16 + (lane & 15)];
+        // this step's input contribution, fetched while the MFMAs run
+        float gxv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cell_thread) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                gxv[g] = a.gx[((size_t)t * 4 * kLstmH + g * kLstmH + u0 + cu) * BP + cb];
+        }
+#pragma unroll
+        for (int ks = 0; ks < kLstmKS; ++ks) {
+            const float av = s_a[(wave * kLstmKS + ks) * 64 + lane];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[ks][ct], acc[ct], 0, 0, 0);
+        }
+        // D: col = lane&15, row = 4*(lane>>4) + i
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_p[wave][4 * (lane >> 4) + i][ct * 16 + (lane & 15)] = acc[ct][i];
+        __syncthreads();
+        // ---- gates, cell, new state ----
+        if (cell_thread) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pre[g] = gxv[g] + ((s_p[0][g * 4 + cu][cb] + s_p[1][g * 4 + cu][cb]) + (s_p[2][g * 4 + cu][cb] + s_p[3][g * 4 + cu][cb]));
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            c = fg * c + ig * gg;
+            a.hfull[((size_t)(t + 1) * kLstmH + u0 + cu) * BP + cb] = og * tanhf(c);
+        }
+        alive = grid_barrier(a.sync, (unsigned)a.nwg * (unsigned)(t + 1), &s_flag);
+    }
+    if (!alive && cell_thread)        // poison the result so an aborted run cannot pass for a finished one
+        a.hfull[((size_t)a.T * kLstmH + u0 + cu) * BP + cb] = __builtin_nanf("");
+}
+
+}  // namespace unetmi
+
+using namespace unetmi;
+
+extern "C" int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float* gx, float* hfull,
+                                      void* sync_ws, void* stream) {
+    if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence: bad sizes");
+    if (H != kLstmH) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: built for hidden size 640");
+    if (BP % 16 != 0 || BP > 64) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: padded batch must be 16, 32, 48 or 64");
+    if (T == 0) return UNETMI_OK;
+    if (!wrec || !gx || !hfull || !sync_ws) return api_fail(UNETMI_E_BAD_ARG, "lstm_recurrence: null pointer");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return api_fail(UNETMI_E_HIP, "lstm_recurrence: cannot query the device");
+    LstmArgs a{};
+    a.wrec = wrec; a.gx = gx; a.hfull = hfull; a.sync = static_cast<unsigned*>(sync_ws);
+    a.T = T; a.BP = BP; a.nwg = H / 4;
+    // the device-wide barrier needs every workgroup resident at once: one per compute unit
+    if (a.nwg > cus) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: fewer compute units than workgroups");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(sync_ws, 0, 2 * sizeof(unsigned), s);
+    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence memset: ") + hipGetErrorString(e));
+    switch (BP / 16) {
+        case 1: hipLaunchKernelGGL(lstm_recurrence_kernel<1>, dim3(a.nwg), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(lstm_recurrence_kernel<2>, dim3(a.nwg), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(lstm_recurrence_kernel<3>, dim3(a.nwg), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(lstm_recurrence_kernel<4>, dim3(a.nwg), dim3(256), 0, s, a); break;
+    }
+    e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_recurrence launch: ") + hipGetErrorString(e));
+}
