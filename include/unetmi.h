@@ -171,8 +171,8 @@ int unetmi_pwconv64_fwd(int N, int H, int W, const float* x, const float* x2, co
  *   wrec[4H][H]      = W_hh W_hr                                       (recurrent and projection matrix folded)
  * and reads the pre-projection states back:  hfull[t+1][u][b] = o_t * tanh(c_t);  h_t = W_hr hfull[t+1].
  * hfull is [T+1][H][BP] with slot 0 = the initial state (zeros for the reference's call); BP = batch padded to
- * a multiple of 16 (<= 64; padded columns compute on zeros and are ignored).  sync_ws: 8 bytes of device
- * scratch (cleared by the call).  H must be 640.  All workgroups have to be resident at once (H/4 <= number of
+ * a multiple of 16 (<= 64; padded columns compute on zeros and are ignored).  sync_ws: 4 * (H/4 + 1) bytes of
+ * device scratch (cleared by the call).  H must be 640.  All workgroups have to be resident at once (H/4 <= number of
  * compute units); the call refuses otherwise.  If the device-wide barrier inside ever times out the last slot
  * of hfull is filled with NaN. */
 int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, void* sync_ws,

@@ -10,8 +10,8 @@
 // operand order for all T steps, its cell state stays in registers.  Per step each of its 4 waves multiplies
 // a quarter of the K range with v_mfma_f32_16x16x4_f32 (B operand = hfull_{t-1}, read straight from L2 into
 // registers), the partial sums meet in LDS, 4 x batch threads apply the gate nonlinearities and write the
-// new hfull rows, and the H/4 workgroups meet at a device-wide barrier (one atomic counter, release /
-// acquire fences).  The barrier spin is bounded: after the limit a workgroup raises an abort flag that
+// new hfull rows, and the H/4 workgroups meet at a device-wide barrier (per-workgroup flag words, coherent
+// loads and stores).  The barrier spin is bounded: after the limit a workgroup raises an abort flag that
 // releases every other workgroup, and the output is poisoned with NaN, so the grid always drains.
 #include <hip/hip_runtime.h>
 
@@ -28,38 +28,47 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLstmH = 640;              // hidden size the kernel is built for
 constexpr int kLstmKS = kLstmH / 16;     // 16x16x4 k-steps per wave (K split over 4 waves)
-constexpr unsigned kSpinLimit = 1u << 22;
+constexpr unsigned kSpinLimit = 1u << 21;
 
 struct LstmArgs {
     const float* wrec;     // [4H][H] folded recurrent matrix, row g*H + u
     const float* gx;       // [T][4H][BP] input contribution incl. both biases
     float* hfull;          // [T+1][H][BP]; slot 0 = initial state, step t reads slot t and writes slot t+1
-    unsigned* sync;        // [0] arrival counter, [1] abort flag
+    unsigned* sync;        // [nwg] step each workgroup has finished, then [1] abort flag
     int T, BP, nwg;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-// Device-wide barrier over the nwg co-resident workgroups.  Returns false when aborted.
-__device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, int* s_flag) {
-    __threadfence();                       // release: this thread's hfull stores become visible device-wide
+// Device-wide barrier over the nwg co-resident workgroups, without a shared counter (same-address
+// atomics from 160 workgroups on 8 dies serialise at the memory side): every workgroup publishes the
+// step it has finished in its own flag word, and wave 0 of every workgroup polls all the flags with
+// coherent loads.  The state rows themselves are written with device-coherent stores, so no cache
+// write-back / invalidate is needed, only that the stores have completed before the flag is raised.
+// Returns false when aborted (bounded spin).
+__device__ __forceinline__ bool grid_barrier(unsigned* flags, int nwg, unsigned step, int* s_flag) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this thread's stores have completed
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&sync[0], 1u);
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        if (tid == 0) __hip_atomic_store(&flags[blockIdx.x], step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         int ok = 1;
-        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++spins > kSpinLimit) {
-                atomicExch(&sync[1], 1u);
+        for (;;) {
+            bool here = true;
+            for (int i = tid; i < nwg; i += 64)
+                here = here && __hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= step;
+            if (__all(here)) break;
+            const unsigned stop = __hip_atomic_load(&flags[nwg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stop != 0u || ++spins > kSpinLimit) {
+                if (tid == 0) __hip_atomic_store(&flags[nwg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
         }
-        *s_flag = ok;
+        if (tid == 0) *s_flag = ok;
     }
     __syncthreads();
-    __threadfence();                       // acquire: later loads observe the other workgroups' stores
     return *s_flag != 0;
 }
 
@@ -96,7 +105,8 @@ __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs 
         for (int ks = 0; ks < kLstmKS; ++ks)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
-                bv[ks][ct] = hprev[(size_t)(4 * (wave * kLstmKS + ks) + (lane >> 4)) * BP + ct * 16 + (lane & 15)];
+                bv[ks][ct] = __hip_atomic_load(&hprev[(size_t)(4 * (wave * kLstmKS + ks) + (lane >> 4)) * BP + ct * 16 + (lane & 15)],
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // this step's input contribution, fetched while the MFMAs run
         float gxv[4] = {0.f, 0.f, 0.f, 0.f};
         if (cell_thread) {
@@ -124,9 +134,10 @@ __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs 
                 pre[g] = gxv[g] + ((s_p[0][g * 4 + cu][cb] + s_p[1][g * 4 + cu][cb]) + (s_p[2][g * 4 + cu][cb] + s_p[3][g * 4 + cu][cb]));
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
             c = fg * c + ig * gg;
-            a.hfull[((size_t)(t + 1) * kLstmH + u0 + cu) * BP + cb] = og * tanhf(c);
+            __hip_atomic_store(&a.hfull[((size_t)(t + 1) * kLstmH + u0 + cu) * BP + cb], og * tanhf(c), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
-        alive = grid_barrier(a.sync, (unsigned)a.nwg * (unsigned)(t + 1), &s_flag);
+        alive = grid_barrier(a.sync, a.nwg, (unsigned)(t + 1), &s_flag);
     }
     if (!alive && cell_thread)        // poison the result so an aborted run cannot pass for a finished one
         a.hfull[((size_t)a.T * kLstmH + u0 + cu) * BP + cb] = __builtin_nanf("");
@@ -152,7 +163,7 @@ extern "C" int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, c
     // the device-wide barrier needs every workgroup resident at once: one per compute unit
     if (a.nwg > cus) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: fewer compute units than workgroups");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(sync_ws, 0, 2 * sizeof(unsigned), s);
+    hipError_t e = hipMemsetAsync(sync_ws, 0, (size_t)(a.nwg + 1) * sizeof(unsigned), s);
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence memset: ") + hipGetErrorString(e));
     switch (BP / 16) {
         case 1: hipLaunchKernelGGL(lstm_recurrence_kernel<1>, dim3(a.nwg), dim3(256), 0, s, a); break;

@@ -49,7 +49,7 @@ def lstm_forward(lstm, x, cache):
     with torch.no_grad():
         seq = torch.zeros((T, x.shape[2], BP), dtype=torch.float32, device=dev)      # [T, in, BP]
         seq[:, :, :B] = x.permute(1, 2, 0)
-        sync = torch.empty(2, dtype=torch.int32, device=dev)
+        sync = torch.empty(lstm.hidden_size // 4 + 1, dtype=torch.int32, device=dev)
         for layer in range(lstm.num_layers):
             w_ih = getattr(lstm, "weight_ih_l{}".format(layer)).detach()
             w_hr = getattr(lstm, "weight_hr_l{}".format(layer)).detach()
