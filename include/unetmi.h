@@ -7,8 +7,8 @@
  * and never allocates device memory: activations, packed weights and
  * workspaces are owned by the caller.  Return value 0 = success, negative =
  * UNETMI_E_* ; unetmi_last_error() gives the message of the calling thread's
- * last failure.  All tensors are fp32, NCHW contiguous, [B, C, F, T] with the
- * time axis innermost -- the layout of the reference's modules
+ * last failure.  All tensors are NCHW contiguous, [B, C, F, T] with the time axis innermost,
+ * fp32 unless a call says bfloat16 storage (UNETMI_DTYPE_BF16 below) -- the layout of the reference's modules
  * (UNet.py:75, cRFUNet.py:280, ResUNet.py:162).
  *
  * Each function names the reference call sites it replaces.  The reference has
@@ -49,6 +49,15 @@ enum {
     UNETMI_ACT_SIGMOID = 5,
     UNETMI_ACT_TANH = 6,
     UNETMI_ACT_GELU = 7      /* erf form */
+};
+
+/* Storage type of the ACTIVATION tensors of a call (inputs, residual, output).  Arithmetic is fp32 in
+ * both cases; parameters, folded BatchNorm vectors and packed weights are always fp32.  With
+ * UNETMI_DTYPE_BF16 the tensors hold bfloat16 (widened exactly on load, rounded to nearest-even on
+ * store) and the pointers below, typed for the fp32 case, address 2-byte elements. */
+enum {
+    UNETMI_DTYPE_F32 = 0,
+    UNETMI_DTYPE_BF16 = 1
 };
 
 /* How the second input tensor combines with the first. */
@@ -92,7 +101,7 @@ typedef struct UnetmiConvDesc {
     int32_t act_param_per_channel; /* 1: act_param has K entries, 0: one     */
     int32_t has_gate;
     int32_t has_residual;
-    int32_t reserved[3];
+    int32_t reserved[3];     /* reserved[0] = UNETMI_DTYPE_* of in0 / in1 / residual / out; others 0 */
 } UnetmiConvDesc;
 
 int unetmi_version(void);
@@ -138,8 +147,8 @@ int unetmi_conv2d_fwd(const UnetmiConvDesc* d,
  * in/in2/out: device fp32 [N,C,H,W] (in2 null, or an addend summed into the input on the fly);
  * weight: device fp32 [C,1,kh,kw] (torch layout); bias: [C] or null. */
 int unetmi_dwconv2d_fwd(int N, int C, int H, int W, int kh, int kw, int ph, int pw, int dh, int dw,
-                        const float* in, const float* in2, const float* weight, const float* bias, float* out,
-                        void* stream);
+                        const void* in, const void* in2, const float* weight, const float* bias, void* out,
+                        int dtype, void* stream);
 
 /* One layer of UNet_m.ResBlock, fused (C = 64):
  *   out = [x (+ x2) +] BN(PReLU(Conv2d(C,C,1)(Conv2d(C,C,(3,3),pad (1,d),dil (1,d),groups=C)(x (+ x2)))))
@@ -150,10 +159,10 @@ int unetmi_dwconv2d_fwd(int N, int C, int H, int W, int kh, int kw, int ph, int 
  * block (ResUNet.py:209).  dilation_w in {1,2,4,8,16}.  dw_weight [C,1,3,3], pw_weight [C,C,1,1] (torch
  * layouts), dw_bias / pw_bias [C] or null, prelu_alpha [1], bn_scale / bn_shift [C]; out must not alias
  * x or x2; x2 and residual are not combined (the reference never does).  Returns UNETMI_E_UNSUPPORTED for other channel counts (use the unfused entry points). */
-int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const float* x, const float* x2,
+int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const void* x, const void* x2,
                               const float* dw_weight, const float* dw_bias, const float* pw_weight,
                               const float* pw_bias, const float* prelu_alpha, const float* bn_scale,
-                              const float* bn_shift, int residual, float* out, void* stream);
+                              const float* bn_shift, int residual, void* out, int dtype, void* stream);
 
 /* Pointwise (1x1, stride 1) convolution 64 -> 64 channels with the fused epilogue, as one bandwidth-bound
  * pass: out = epilogue(weight[64,64] . (x (+ x2)) + bias) (+ x when residual).  The epilogue is
@@ -161,9 +170,9 @@ int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const 
  * ResUNet.py:125-132 through UNet_m.py:340-345) or act(v) * scale + shift when act_first = 1; act is
  * LeakyReLU / single-parameter PReLU with slope leaky_slope[0], or the identity when leaky_slope is null.
  * Same tensors as unetmi_conv2d_fwd would take for that layer, except weight in torch layout [64,64,1,1]. */
-int unetmi_pwconv64_fwd(int N, int H, int W, const float* x, const float* x2, const float* weight, const float* bias,
+int unetmi_pwconv64_fwd(int N, int H, int W, const void* x, const void* x2, const float* weight, const float* bias,
                         const float* scale, const float* shift, const float* leaky_slope, int act_first, int residual,
-                        float* out, void* stream);
+                        void* out, int dtype, void* stream);
 
 /* Time recurrence of one layer of a projected LSTM (nn.LSTM(..., hidden 640, proj_size P), the bottleneck of
  * ResUNet.py:139,186-197) as one persistent launch.  The caller does the time-parallel parts as GEMMs:
@@ -182,14 +191,14 @@ int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float*
  * written into channels [c_off, c_off+C) of out[N,C_out,F,T].  Replaces
  *   permute -> nn.LayerNorm(257) on [B,C,T,F] -> permute -> torch.cat       ResUNet.py:165-175, :49, :53
  * with the two permutes folded into the indexing and the cat into the channel offset. */
-int unetmi_layernorm_f_fwd(int N, int C, int F, int T, int C_out, int c_off, float eps, const float* x,
-                           const float* gamma, const float* beta, float* out, void* stream);
+int unetmi_layernorm_f_fwd(int N, int C, int F, int T, int C_out, int c_off, float eps, const void* x,
+                           const float* gamma, const float* beta, void* out, int dtype, void* stream);
 
 /* out[n,k,f,t] = (tanh(y[n,k,f,t]) + eps) * x[n,k,f,t] with x holding Cx >= K channels of which
  * the first K are used.  Replaces  mask = tanh(y) + 1e-13 ; output = mask * input[:, :2]
  *   ResUNet.py:217-219.   y, out: [N,K,F,T]; x: [N,Cx,F,T]; device fp32. */
-int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const float* y, const float* x, float* out,
-                         void* stream);
+int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const void* y, const void* x, void* out,
+                         int dtype, void* stream);
 
 /* Complex ratio filter / complex mask application over the STFT:
  *   Y[b,n,c,f,t] = sum_{p<PF, q<PT} Hf[b,n,c,p,q,f,t] * X[b,c,f+p-(PF-1)/2, t+q-(PT-1)/2]   (zero outside)

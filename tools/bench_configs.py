@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="activation storage of the resunet / dsunet workloads (arithmetic is fp32 either way)")
     args = ap.parse_args()
     import unet_amd
     from unet_amd.ops import crf_apply
@@ -51,9 +53,11 @@ def main():
     B = args.batch
     g = torch.Generator().manual_seed(4321)
 
-    def report(name, sec, gflop, workload):
+    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    def report(name, sec, gflop, workload, dtype="f32"):
         print(json.dumps({"workload": name, "value": B * AUDIO_SECONDS / sec, "unit": "audio-s/s",
-                          "ms_per_step": 1e3 * sec, "batch": B, "dtype": "f32",
+                          "ms_per_step": 1e3 * sec, "batch": B, "dtype": dtype,
                           "gflop_per_utterance": gflop, "tflops": gflop * B / sec / 1e3,
                           "config": workload}), flush=True)
 
@@ -73,21 +77,21 @@ def main():
             net = unet_amd.ResUNet()
             unet_amd.seeded_fill_(net, seed=31)
             net.eval().to(dev)
-            x = torch.randn((B, 4, 257, 501), generator=g).to(dev)
+            x = torch.randn((B, 4, 257, 501), generator=g).to(dev).to(act)
             sec = timed(lambda: net(x), args.steps, args.warmup)
-            report("resunet", sec, 46.0, "ResUNet() forward, [B,4,257,501]")
+            report("resunet", sec, 46.0, "ResUNet() forward, [B,4,257,501]", args.dtype)
             del net, x
         if args.only in (None, "dsunet"):
             net = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8))
             unet_amd.seeded_fill_(net, seed=41)
             net.eval().to(dev)
-            sf = torch.randn((B, 8, 257, 512), generator=g).to(dev)
+            sf = torch.randn((B, 8, 257, 512), generator=g).to(dev).to(act)
             SV = torch.randn((B, 4, 514), generator=g).to(dev)
             ang = torch.rand((B,), generator=g) * 2 * math.pi
             theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1).to(dev)
             sec = timed(lambda: net(sf, SV, theta), args.steps, args.warmup)
             report("dsunet", sec, 129.76, "DSUNet(UDSS table, model_complexity 45, 8 inputs) forward, "
-                                          "sf [B,8,257,512], SV [B,4,514], theta [B,2]")
+                                          "sf [B,8,257,512], SV [B,4,514], theta [B,2]", args.dtype)
 
 
 if __name__ == "__main__":

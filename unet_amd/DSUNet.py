@@ -182,19 +182,19 @@ class DSUNet(nn.Module):
 
     def forward(self, sf, SV, theta):
         require_device_tensor(sf, "DSUNet")
-        attract = self.Attractor(SV, theta)
+        attract = self.Attractor(SV.float(), theta.float())            # tiny fp32 side network, whatever sf's storage
         L = self.n_layer
         skips = []
         for i, enc in enumerate(self.encoders):
             skips.append(self.res[i](sf) if i != L - 1 else sf)
-            gate = self.attractEncoders[i](attract).contiguous()      # [B, C_out]
+            gate = self.attractEncoders[i](attract).float().contiguous()      # [B, C_out]
             sf = enc(sf, gate=gate)                                    # dropout p=0 is the identity in eval
         p = self.BTN(sf)
         for i, dec in enumerate(self.decoders):
             p = dec(p) if i == 0 else dec(p, skips[L - i])
         if self._head is None:
             object.__setattr__(self, "_head", FusedConv(self.linear, None, self.mask.squash))
-        m = self._head(p)                                              # [B, 2, F, T], squashed
+        m = self._head(p).float()                                      # [B, 2, F, T], squashed (complex64 output)
         return torch.complex(m[:, 0, ...], m[:, 1, ...])
 
     def masking(self, X, M):

@@ -68,14 +68,14 @@ class ResUNet(nn.Module):
             fused = FusedConv(enc.conv, enc.bn, enc.acti, swap_hw=True)
             object.__setattr__(self, cache_name, fused)
         ln = branch[1]
-        layernorm_f(fused(x), ln.weight, ln.bias, ln.eps, out, c_off)
+        layernorm_f(fused(x), ln.weight.float(), ln.bias.float(), ln.eps, out, c_off)
 
     def forward(self, input):
         require_device_tensor(input, "ResUNet")
         if self.training:
             raise NotImplementedError("ResUNet: train-mode forward is not available in this build; call .eval()")
         B, _, F, T = input.shape
-        x = torch.empty((B, 64, F, T), dtype=torch.float32, device=input.device)
+        x = torch.empty((B, 64, F, T), dtype=input.dtype, device=input.device)
         self._input_branch(self.layer_data, "_in_data", input[:, :-2].contiguous(), x, 0)
         self._input_branch(self.layer_AF, "_in_af", input[:, -2:].contiguous(), x, 20)
 
@@ -90,7 +90,7 @@ class ResUNet(nn.Module):
         # recurrence (unet_amd/lstm.py); an LSTM of another shape runs torch's device implementation
         seq = x.reshape(x.shape[0], x.shape[1], x.shape[3]).permute(0, 2, 1)
         if lstm_supported(self.bottleneck):
-            seq = lstm_forward(self.bottleneck, seq, self._lstm_cache)
+            seq = lstm_forward(self.bottleneck, seq.float(), self._lstm_cache).to(x.dtype)
         else:
             seq = self.bottleneck(seq)[0]
         y = seq.permute(0, 2, 1).reshape(x.shape[0], x.shape[1], 1, x.shape[3]).contiguous()
@@ -113,4 +113,8 @@ class ResUNet(nn.Module):
 
         if self._out is None:
             object.__setattr__(self, "_out", FusedConv(self.out_layer))
+        if y.dtype != torch.float32:
+            # bfloat16 storage: the mask logits feed a tanh, so the last (thin) layer and the mask run
+            # on widened tensors and only the final product is rounded
+            return tanh_mask_mul(self._out(y.float()), input.float().contiguous(), 1e-13).to(y.dtype)
         return tanh_mask_mul(self._out(y), input.contiguous(), 1e-13)

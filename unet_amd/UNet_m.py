@@ -180,8 +180,8 @@ class ResBlock(nn.Module):
         for i, layer in enumerate(self.layers):
             dw = layer[0]
             src = x if i == 0 else r
-            t = dwconv2d_fwd(src, add if i == 0 else None, dw.weight, dw.bias, list(_pair(dw.padding)),
-                             list(_pair(dw.dilation)))
+            t = dwconv2d_fwd(src, add if i == 0 else None, dw.weight.float(), None if dw.bias is None else dw.bias.float(),
+                             list(_pair(dw.padding)), list(_pair(dw.dilation)))
             r = self._fused[i](t, residual=r)        # layer 0 has no running value to add
         return r
 
@@ -190,6 +190,7 @@ class ResBlock(nn.Module):
         for i, layer in enumerate(self.layers):
             dw, pw = layer[0], layer[1]
             st = self._fused[i]._prepare(x.device)      # folded BatchNorm scale/shift, PReLU parameter on device
-            r = resblock_layer(x if i == 0 else r, add if i == 0 else None, dw.weight, dw.bias, pw.weight, pw.bias,
-                               st["act_param"], st["scale"], st["shift"], int(_pair(dw.dilation)[1]), i > 0)
+            f32 = lambda t: None if t is None else (t if t.dtype == torch.float32 else t.float())  # noqa: E731
+            r = resblock_layer(x if i == 0 else r, add if i == 0 else None, f32(dw.weight), f32(dw.bias), f32(pw.weight),
+                               f32(pw.bias), st["act_param"], st["scale"], st["shift"], int(_pair(dw.dilation)[1]), i > 0)
         return r

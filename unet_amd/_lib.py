@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libunetmi.so")
 # activation / input-mode codes of include/unetmi.h
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SILU, ACT_SOFTPLUS, ACT_SIGMOID, ACT_TANH, ACT_GELU = range(8)
 IN_SINGLE, IN_CONCAT, IN_ADD = range(3)
+DTYPE_F32, DTYPE_BF16 = 0, 1
 
 EXPORTED_SYMBOLS = (
     "unetmi_version",
@@ -75,9 +76,9 @@ def _load():
     lib.unetmi_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 10 + [vp]
     lib.unetmi_conv2d_fwd.restype = ctypes.c_int
     ci, cf = ctypes.c_int, ctypes.c_float
-    lib.unetmi_dwconv2d_fwd.argtypes = [ci] * 10 + [fp] * 5 + [vp]
-    lib.unetmi_layernorm_f_fwd.argtypes = [ci] * 6 + [cf] + [fp] * 4 + [vp]
-    lib.unetmi_tanh_mask_mul.argtypes = [ci] * 5 + [cf] + [fp] * 3 + [vp]
+    lib.unetmi_dwconv2d_fwd.argtypes = [ci] * 10 + [fp] * 5 + [ci, vp]
+    lib.unetmi_layernorm_f_fwd.argtypes = [ci] * 6 + [cf] + [fp] * 4 + [ci, vp]
+    lib.unetmi_tanh_mask_mul.argtypes = [ci] * 5 + [cf] + [fp] * 3 + [ci, vp]
     lib.unetmi_crf_apply.argtypes = [ci] * 7 + [fp] * 3 + [vp]
     sz, ll = ctypes.c_size_t, ctypes.c_longlong
     lib.unetmi_bn_workspace_bytes.argtypes = [ci] * 3
@@ -88,9 +89,9 @@ def _load():
     lib.unetmi_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.unetmi_conv2d_wgrad_workspace_bytes.restype = sz
     lib.unetmi_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 4 + [vp, sz, vp]
-    lib.unetmi_resblock_layer_fwd.argtypes = [ci] * 5 + [fp] * 9 + [ci, fp, vp]
+    lib.unetmi_resblock_layer_fwd.argtypes = [ci] * 5 + [fp] * 9 + [ci, fp, ci, vp]
     lib.unetmi_resblock_layer_fwd.restype = ctypes.c_int
-    lib.unetmi_pwconv64_fwd.argtypes = [ci] * 3 + [fp] * 7 + [ci, ci, fp, vp]
+    lib.unetmi_pwconv64_fwd.argtypes = [ci] * 3 + [fp] * 7 + [ci, ci, fp, ci, vp]
     lib.unetmi_pwconv64_fwd.restype = ctypes.c_int
     lib.unetmi_lstm_recurrence.argtypes = [ci] * 3 + [fp] * 3 + [vp, vp]
     lib.unetmi_lstm_recurrence.restype = ctypes.c_int

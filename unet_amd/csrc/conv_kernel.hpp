@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "conv_plan.hpp"
+#include "io_types.hpp"
 
 namespace unetmi {
 
@@ -29,6 +30,7 @@ struct ConvArgs {
     unsigned blk_end[kMaxPhase];      // exclusive prefix end of each row phase's blocks
     unsigned magic_ncols, magic_nrows;  // ceil(2^32 / d) for division of small numbers
     int xcd_remap;                      // 1: one XCD walks a contiguous run of tiles
+    int bf16;                           // activations (in0, in1, residual, out) stored as bfloat16
 #ifdef UNETMI_ABLATE
     int ablate;                        // developer probe only (tools/conv_probe.hip)
     unsigned long long* stamps;
@@ -238,7 +240,7 @@ __device__ __forceinline__ void group_mfma2(f32x16 (&acc0)[TPG], f32x16 (&acc1)[
 
 // Fused epilogue: bias, BatchNorm affine and activation (either order), gate, residual,
 // store.  Lane = one time column, register = one output channel (MFMA C/D layout).
-template <int NG, int TPG>
+template <int NG, int TPG, bool BF16 = false>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NG][TPG], const ConvArgs& p,
                                               const float* s_par, int n, int cb, int a, int i0, int j0,
                                               int wm, int wn, int half, int j) {
@@ -271,15 +273,16 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NG][TPG], cons
                 else             v = apply_act(v * e_sc[r] + e_sf[r], p.act, e_sl[r]);
                 v *= e_g[r];
                 const size_t o = chan + (size_t)oh * p.OW + ow;
-                if (p.residual) v += p.residual[o];
-                if (!ABLATE(4) || v == 123.456f) p.out[o] = v;
+                if (p.residual) v += ld_act<BF16>(p.residual, o);
+                if (!ABLATE(4) || v == 123.456f) st_act<BF16>(p.out, o, v);
             }
         }
     }
 }
 
-template <int NG, int TPG, int WM, int WN, bool TWO, int NTW0, int NTW1>
+template <int NG, int TPG, int WM, int WN, bool TWO, int NTW0, int NTW1, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
+    constexpr int EB = BF16 ? 2 : 4;              // bytes of a stored activation
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
     float* s_w = smem + p.in_tile_floats;
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         const int r = rr - cl * p.nrows;
         const int grow = row0 + r, gcol = col0 + c;
         const bool ok = e < in_elems && (unsigned)grow < (unsigned)p.H && (unsigned)gcol < (unsigned)p.W;
-        voff[s] = ok ? (cl * HW + grow * p.W + gcol) * 4 : kOutside;
+        voff[s] = ok ? (cl * HW + grow * p.W + gcol) * EB : kOutside;
     }
     float rin[kMaxInSlots];
     float rin2[TWO ? kMaxInSlots : 1];
@@ -380,19 +383,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         const int ch1 = (TWO && p.in_mode == UNETMI_IN_ADD) ? ch0 : 0;
         const long long first1 = first0;
         const int shift1 = 0;
-        const float* base0 = second ? p.in1 : p.in0;
+        const char* base0 = reinterpret_cast<const char*>(second ? p.in1 : p.in0);
         const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(base0 + first0 * HW), 0, live ? ch0 * HW * 4 : 0, 0x00020000);
+            const_cast<char*>(base0 + first0 * HW * EB), 0, live ? ch0 * HW * EB : 0, 0x00020000);
 #pragma unroll
-        for (int s = 0; s < kMaxInSlots; ++s)
-            rin[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, voff[s], 0, 0));
+        for (int s = 0; s < kMaxInSlots; ++s) rin[s] = buf_ld_act<BF16>(rs0, voff[s], 0);
         if (TWO) {
             const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(p.in1 + first1 * HW), 0, live ? ch1 * HW * 4 : 0, 0x00020000);
+                const_cast<char*>(reinterpret_cast<const char*>(p.in1) + first1 * HW * EB), 0,
+                live ? ch1 * HW * EB : 0, 0x00020000);
 #pragma unroll
-            for (int s = 0; s < kMaxInSlots; ++s)
-                rin2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    rs1, voff[s] + shift1, 0, 0));
+            for (int s = 0; s < kMaxInSlots; ++s) rin2[s] = buf_ld_act<BF16>(rs1, voff[s] + shift1, 0);
         }
         const auto rsw = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(wsrc_base + (size_t)(live ? chunk : 0) * chunk_w_floats), 0,
@@ -454,16 +455,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 
     STAMP(6);                      // MFMA loops (all chunks)
     // ---- epilogue ---------------------------------------------------------------
-    conv_epilogue<NG, TPG>(acc, p, s_par, n, cb, a, i0, j0, wm, wn, half, j);
+    conv_epilogue<NG, TPG, BF16>(acc, p, s_par, n, cb, a, i0, j0, wm, wn, half, j);
     STAMP(7);                      // epilogue
 #ifdef UNETMI_ABLATE
     if (p.stamps && threadIdx.x == 0) atomicAdd(&p.stamps[8], 1ull);
 #endif
 }
 
-template <int NG, int TPG, int WM, int WN, bool TWO, int NTW0, int NTW1>
+template <int NG, int TPG, int WM, int WN, bool TWO, int NTW0, int NTW1, bool BF16 = false>
 inline void launch_conv_variant(unsigned grid, size_t lds, hipStream_t stream, const ConvArgs& p) {
-    hipLaunchKernelGGL((conv_mfma_kernel<NG, TPG, WM, WN, TWO, NTW0, NTW1>), dim3(grid), dim3(256), lds,
+    hipLaunchKernelGGL((conv_mfma_kernel<NG, TPG, WM, WN, TWO, NTW0, NTW1, BF16>), dim3(grid), dim3(256), lds,
                        stream, p);
 }
 

@@ -62,6 +62,7 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
     p.in_tile_floats = pl.in_tile_floats; p.w_tile_floats = pl.w_tile_floats; p.njt = pl.njt;
     p.magic_ncols = magic_u32(pl.ncols); p.magic_nrows = magic_u32(pl.nrows);
     p.xcd_remap = g_xcd_remap >= 0 ? g_xcd_remap : 0;
+    p.bf16 = d.reserved[0] == UNETMI_DTYPE_BF16;
 #ifdef UNETMI_ABLATE
     p.ablate = g_ablate;
     p.stamps = g_stamps;
@@ -71,7 +72,9 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
     // two loads per input element: the skip add
     const bool two = needs_two_loads(d, pl);
     bool done = false;
-    if (two || g_force_staged) {
+    if (p.bf16) {
+        done = launch_conv_staged(pl.NG, pl.WN, two, total, pl.lds_bytes, stream, p);
+    } else if (two || g_force_staged) {
         done = launch_conv_staged(pl.NG, pl.WN, true, total, pl.lds_bytes, stream, p);
     } else {
         const size_t lds = pl.lds_bytes_dma;

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "conv_plan.hpp"
+#include "io_types.hpp"
 
 namespace unetmi {
 
@@ -40,8 +41,9 @@ __device__ __forceinline__ float direct_act(float v, int act, float slope) {
     }
 }
 
-template <int RPT, int KT, int KH>
+template <int RPT, int KT, int KH, bool BF16>
 __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectArgs p) {
+    constexpr int EB = BF16 ? 2 : 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ow = blockIdx.x * 64 + lane;
@@ -68,17 +70,18 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectArgs p) {
     }
 
     for (int ci = 0; ci < p.Ctot; ++ci) {
-        const float* src;
-        const float* src2 = nullptr;
-        if (p.in_mode == UNETMI_IN_CONCAT && ci >= p.C0) src = p.in1 + ((size_t)n * p.C1 + (ci - p.C0)) * HW;
-        else src = p.in0 + ((size_t)n * p.C0 + ci) * HW;
-        if (p.in_mode == UNETMI_IN_ADD) src2 = p.in1 + ((size_t)n * p.C0 + ci) * HW;
+        const char* src;
+        const char* src2 = nullptr;
+        if (p.in_mode == UNETMI_IN_CONCAT && ci >= p.C0)
+            src = reinterpret_cast<const char*>(p.in1) + ((size_t)n * p.C1 + (ci - p.C0)) * HW * EB;
+        else src = reinterpret_cast<const char*>(p.in0) + ((size_t)n * p.C0 + ci) * HW * EB;
+        if (p.in_mode == UNETMI_IN_ADD) src2 = reinterpret_cast<const char*>(p.in1) + ((size_t)n * p.C0 + ci) * HW * EB;
         float x[NX];
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
             const int o = roff[q] < 0 ? 0 : roff[q];
-            float v = src[o];
-            if (src2) v += src2[o];
+            float v = ld_act<BF16>(src, o);
+            if (src2) v += ld_act<BF16>(src2, o);
             x[q] = roff[q] < 0 ? 0.f : v;
         }
         const float* wrow = p.w + (size_t)ci * KH * p.kpad + k0;
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectArgs p) {
             else             v = direct_act(v * sc + sf, p.act, slope);
             v *= gt;
             const size_t o = chan + (size_t)oh * p.W + ow;
-            if (p.residual) v += p.residual[o];
-            p.out[o] = v;
+            if (p.residual) v += ld_act<BF16>(p.residual, o);
+            st_act<BF16>(p.out, o, v);
         }
     }
 }
@@ -129,11 +132,13 @@ hipError_t launch_direct_conv(const UnetmiConvDesc& d, const ConvPlan& pl,
     p.in_mode = d.in_mode; p.act = d.act; p.act_first = d.act_first; p.act_pc = d.act_param_per_channel;
     p.pad = pl.direct_pad; p.kpad = pl.direct_kpad; p.nkt = pl.direct_kpad / pl.direct_kt;
     const int rpt = pl.direct_rpt, kt = pl.direct_kt, kh = d.kh;
+    const bool bf16 = d.reserved[0] == UNETMI_DTYPE_BF16;
     const dim3 grid((d.W + 63) / 64, (d.OH + 4 * rpt - 1) / (4 * rpt), (unsigned)d.N * p.nkt);
     if (grid.z > 65535u * 16u) return hipErrorInvalidConfiguration;
 #define UNETMI_DIRECT(RPT_, KT_, KH_)                                                        \
     if (rpt == RPT_ && kt == KT_ && kh == KH_) {                                             \
-        hipLaunchKernelGGL((direct_conv_kernel<RPT_, KT_, KH_>), grid, dim3(256), 0, stream, p); \
+        if (bf16) hipLaunchKernelGGL((direct_conv_kernel<RPT_, KT_, KH_, true>), grid, dim3(256), 0, stream, p); \
+        else hipLaunchKernelGGL((direct_conv_kernel<RPT_, KT_, KH_, false>), grid, dim3(256), 0, stream, p); \
         return hipGetLastError();                                                            \
     }
     UNETMI_DIRECT(8, 1, 1) UNETMI_DIRECT(8, 1, 3) UNETMI_DIRECT(8, 1, 7)

@@ -1,0 +1,47 @@
+// Activation storage types.  Arithmetic is always fp32; BF16 = true means the activation tensors
+// (inputs, residual, output) are stored as bfloat16 in HBM: widened on load (a 16-bit shift, exact),
+// rounded to nearest-even on store.  Parameters and packed weights stay fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace unetmi {
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __builtin_bit_cast(float, (unsigned)b << 16);
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                      // round to nearest even
+    return (unsigned short)(u >> 16);
+}
+
+template <bool BF16>
+__device__ __forceinline__ float ld_act(const void* p, size_t i) {
+    if (BF16) return bf16_bits_to_f32(static_cast<const unsigned short*>(p)[i]);
+    return static_cast<const float*>(p)[i];
+}
+
+template <bool BF16>
+__device__ __forceinline__ void st_act(void* p, size_t i, float v) {
+    if (BF16) static_cast<unsigned short*>(p)[i] = f32_to_bf16_bits(v);
+    else static_cast<float*>(p)[i] = v;
+}
+
+// buffer-descriptor forms: byte offsets scale with the element size; out-of-range lanes read 0 / drop the store
+template <bool BF16>
+__device__ __forceinline__ float buf_ld_act(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    if (BF16) return bf16_bits_to_f32((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+
+template <bool BF16>
+__device__ __forceinline__ void buf_st_act(float v, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    if (BF16) __builtin_amdgcn_raw_buffer_store_b16((short)f32_to_bf16_bits(v), rs, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, 0);
+}
+
+template <bool BF16> constexpr int act_bytes() { return BF16 ? 2 : 4; }
+
+}  // namespace unetmi

@@ -7,22 +7,22 @@
 #include <string>
 
 #include "../../include/unetmi.h"
+#include "io_types.hpp"
 
 namespace unetmi {
 
 // out[n,c,h,w] = b[c] + sum_{kh,kw} (in [+ in2])[n,c,h-ph+kh*dh, w-pw+kw*dw] * wt[c,kh,kw]   (stride 1, groups = C)
-template <int KH, int KW>
-__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ in, const float* __restrict__ in2,
+template <int KH, int KW, bool BF16>
+__global__ __launch_bounds__(256) void dwconv_kernel(const void* __restrict__ in, const void* __restrict__ in2,
                                                      const float* __restrict__ wt,
-                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                     const float* __restrict__ bias, void* __restrict__ out,
                                                      int C, int H, int W, int ph, int pw, int dh, int dw) {
     const int w = blockIdx.x * 256 + threadIdx.x;
     const int h = blockIdx.y;
     const int nc = blockIdx.z;                    // n*C + c
     if (w >= W) return;
     const int c = nc % C;
-    const float* src = in + (size_t)nc * H * W;
-    const float* src2 = in2 ? in2 + (size_t)nc * H * W : nullptr;      // optional addend (x + skip)
+    const size_t base = (size_t)nc * H * W;
     float k[KH * KW];
 #pragma unroll
     for (int i = 0; i < KH * KW; ++i) k[i] = wt[c * KH * KW + i];   // wave-uniform -> scalar loads
@@ -36,45 +36,48 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ i
             const int iw = w - pw + kw * dw;
             float v = 0.f;
             if ((unsigned)iw < (unsigned)W) {
-                v = src[(size_t)ih * W + iw];
-                if (src2) v += src2[(size_t)ih * W + iw];
+                v = ld_act<BF16>(in, base + (size_t)ih * W + iw);
+                if (in2) v += ld_act<BF16>(in2, base + (size_t)ih * W + iw);      // optional addend (x + skip)
             }
             acc = fmaf(v, k[kh * KW + kw], acc);
         }
     }
-    out[(size_t)nc * H * W + (size_t)h * W + w] = acc;
+    st_act<BF16>(out, base + (size_t)h * W + w, acc);
 }
 
 // LayerNorm over F of x[N,C,F,T] (biased variance), written to channels
 // [c_off, c_off + C) of out[N, C_out, F, T].  One thread per (n, c, t) column: two
 // passes over its F values, each a coalesced row read across the wave.
-__global__ __launch_bounds__(256) void layernorm_f_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ out,
+template <bool BF16>
+__global__ __launch_bounds__(256) void layernorm_f_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, void* __restrict__ out,
                                                           int C, int F, int T, int C_out, int c_off, float eps) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int nc = blockIdx.y;
     if (t >= T) return;
     const int n = nc / C, c = nc % C;
-    const float* col = x + (size_t)nc * F * T + t;
+    const size_t col = (size_t)nc * F * T + t;
     float mean = 0.f;
-    for (int f = 0; f < F; ++f) mean += col[(size_t)f * T];
+    for (int f = 0; f < F; ++f) mean += ld_act<BF16>(x, col + (size_t)f * T);
     mean /= (float)F;
     float var = 0.f;
-    for (int f = 0; f < F; ++f) { const float d = col[(size_t)f * T] - mean; var = fmaf(d, d, var); }
+    for (int f = 0; f < F; ++f) { const float d = ld_act<BF16>(x, col + (size_t)f * T) - mean; var = fmaf(d, d, var); }
     const float rstd = rsqrtf(var / (float)F + eps);
-    float* dst = out + ((size_t)n * C_out + c_off + c) * F * T + t;
-    for (int f = 0; f < F; ++f) dst[(size_t)f * T] = (col[(size_t)f * T] - mean) * rstd * gamma[f] + beta[f];
+    const size_t dst = ((size_t)n * C_out + c_off + c) * F * T + t;
+    for (int f = 0; f < F; ++f)
+        st_act<BF16>(out, dst + (size_t)f * T, (ld_act<BF16>(x, col + (size_t)f * T) - mean) * rstd * gamma[f] + beta[f]);
 }
 
 // out[n,k,f,t] = (tanh(y[n,k,f,t]) + eps) * x[n,k,f,t], x having Cx >= K channels (first K used)
-__global__ __launch_bounds__(256) void tanh_mask_kernel(const float* __restrict__ y, const float* __restrict__ x,
-                                                        float* __restrict__ out, int K, int Cx, size_t HW,
+template <bool BF16>
+__global__ __launch_bounds__(256) void tanh_mask_kernel(const void* __restrict__ y, const void* __restrict__ x,
+                                                        void* __restrict__ out, int K, int Cx, size_t HW,
                                                         size_t total, float eps) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const size_t sp = i % HW, nk = i / HW;
     const size_t n = nk / K, k = nk % K;
-    out[i] = (tanhf(y[i]) + eps) * x[(n * Cx + k) * HW + sp];
+    st_act<BF16>(out, i, (tanhf(ld_act<BF16>(y, i)) + eps) * ld_act<BF16>(x, (n * Cx + k) * HW + sp));
 }
 
 // Complex ratio filter: Y[b,n,c,f,t] = sum_{p,q} Hf[b,n,c,p,q,f,t] * X[b,c,f+p-Lf,t+q-Lt]  (zero outside).
@@ -117,8 +120,8 @@ namespace unetmi { int api_fail(int code, const std::string& msg); }
 extern "C" {
 
 int unetmi_dwconv2d_fwd(int N, int C, int H, int W, int kh, int kw, int ph, int pw, int dh, int dw,
-                        const float* in, const float* in2, const float* weight, const float* bias, float* out,
-                        void* stream) {
+                        const void* in, const void* in2, const float* weight, const float* bias, void* out,
+                        int dtype, void* stream) {
     if (N < 0 || C < 1 || H < 1 || W < 1) return api_fail(UNETMI_E_BAD_DESC, "dwconv: bad sizes");
     if (2 * ph != dh * (kh - 1) || 2 * pw != dw * (kw - 1))
         return api_fail(UNETMI_E_UNSUPPORTED, "dwconv: only 'same' padding (2p = d(k-1)) is built");
@@ -127,35 +130,48 @@ int unetmi_dwconv2d_fwd(int N, int C, int H, int W, int kh, int kw, int ph, int 
     if ((long long)N * C > 65535ll * 1024) return api_fail(UNETMI_E_UNSUPPORTED, "dwconv: N*C too large");
     const dim3 grid((W + 255) / 256, H, N * C), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (kh == 3 && kw == 3) hipLaunchKernelGGL((dwconv_kernel<3, 3>), grid, block, 0, s, in, in2, weight, bias, out, C, H, W, ph, pw, dh, dw);
-    else if (kh == 1 && kw == 3) hipLaunchKernelGGL((dwconv_kernel<1, 3>), grid, block, 0, s, in, in2, weight, bias, out, C, H, W, ph, pw, dh, dw);
-    else if (kh == 3 && kw == 1) hipLaunchKernelGGL((dwconv_kernel<3, 1>), grid, block, 0, s, in, in2, weight, bias, out, C, H, W, ph, pw, dh, dw);
-    else return api_fail(UNETMI_E_UNSUPPORTED, "dwconv: kernel size not built (3x3, 1x3, 3x1)");
+    const bool bf = dtype == UNETMI_DTYPE_BF16;
+#define UNETMI_DW(KH_, KW_)                                                                                              \
+    if (kh == KH_ && kw == KW_) {                                                                                        \
+        if (bf) hipLaunchKernelGGL((dwconv_kernel<KH_, KW_, true>), grid, block, 0, s, in, in2, weight, bias, out, C, H, W, ph, pw, dh, dw); \
+        else hipLaunchKernelGGL((dwconv_kernel<KH_, KW_, false>), grid, block, 0, s, in, in2, weight, bias, out, C, H, W, ph, pw, dh, dw);  \
+    } else
+    UNETMI_DW(3, 3) UNETMI_DW(1, 3) UNETMI_DW(3, 1)
+        return api_fail(UNETMI_E_UNSUPPORTED, "dwconv: kernel size not built (3x3, 1x3, 3x1)");
+#undef UNETMI_DW
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("dwconv launch: ") + hipGetErrorString(e));
 }
 
-int unetmi_layernorm_f_fwd(int N, int C, int F, int T, int C_out, int c_off, float eps, const float* x,
-                           const float* gamma, const float* beta, float* out, void* stream) {
+int unetmi_layernorm_f_fwd(int N, int C, int F, int T, int C_out, int c_off, float eps, const void* x,
+                           const float* gamma, const float* beta, void* out, int dtype, void* stream) {
     if (N < 0 || C < 1 || F < 1 || T < 1 || c_off < 0 || c_off + C > C_out)
         return api_fail(UNETMI_E_BAD_DESC, "layernorm: bad sizes");
     if (N == 0) return UNETMI_OK;
     if (!x || !gamma || !beta || !out) return api_fail(UNETMI_E_BAD_ARG, "layernorm: null tensor pointer");
     if ((long long)N * C > 65535) return api_fail(UNETMI_E_UNSUPPORTED, "layernorm: N*C > 65535");
-    hipLaunchKernelGGL(layernorm_f_kernel, dim3((T + 255) / 256, N * C), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       x, gamma, beta, out, C, F, T, C_out, c_off, eps);
+    if (dtype == UNETMI_DTYPE_BF16)
+        hipLaunchKernelGGL(layernorm_f_kernel<true>, dim3((T + 255) / 256, N * C), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           x, gamma, beta, out, C, F, T, C_out, c_off, eps);
+    else
+        hipLaunchKernelGGL(layernorm_f_kernel<false>, dim3((T + 255) / 256, N * C), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           x, gamma, beta, out, C, F, T, C_out, c_off, eps);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("layernorm launch: ") + hipGetErrorString(e));
 }
 
-int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const float* y, const float* x, float* out,
-                         void* stream) {
+int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const void* y, const void* x, void* out,
+                         int dtype, void* stream) {
     if (N < 0 || K < 1 || Cx < K || F < 1 || T < 1) return api_fail(UNETMI_E_BAD_DESC, "tanh_mask: bad sizes");
     if (N == 0) return UNETMI_OK;
     if (!y || !x || !out) return api_fail(UNETMI_E_BAD_ARG, "tanh_mask: null tensor pointer");
     const size_t total = (size_t)N * K * F * T;
-    hipLaunchKernelGGL(tanh_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       y, x, out, K, Cx, (size_t)F * T, total, eps);
+    if (dtype == UNETMI_DTYPE_BF16)
+        hipLaunchKernelGGL(tanh_mask_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           y, x, out, K, Cx, (size_t)F * T, total, eps);
+    else
+        hipLaunchKernelGGL(tanh_mask_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           y, x, out, K, Cx, (size_t)F * T, total, eps);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("tanh_mask launch: ") + hipGetErrorString(e));
 }

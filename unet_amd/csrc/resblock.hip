@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "../../include/unetmi.h"
+#include "io_types.hpp"
 
 namespace unetmi {
 
@@ -37,8 +38,8 @@ constexpr int kRbBPitch = 288;  // pitch of a channel row of the B operand (256 
                                 // lane halves of an MFMA read land in different banks)
 
 struct ResblockArgs {
-    const float* x;
-    const float* x2;        // optional addend of the input (x + x2)
+    const void* x;
+    const void* x2;         // optional addend of the input (x + x2)
     const float* dw_w;      // [64][3][3]
     const float* dw_b;      // [64] or null
     const float* pw_w;      // [64 out][64 in]
@@ -46,7 +47,7 @@ struct ResblockArgs {
     const float* alpha;     // PReLU parameter [1]
     const float* scale;     // folded BatchNorm [64]
     const float* shift;
-    float* out;
+    void* out;
     int N, H, W, residual, act_first;
     int tiles_h, tiles_w, ntiles;
 };
@@ -57,8 +58,9 @@ __device__ __forceinline__ float rb_load(__amdgpu_buffer_rsrc_t rs, int voff, in
 
 // DWISE = false drops the depthwise stage: a plain 64 -> 64 pointwise convolution (D = 0, no halo),
 // whose input chunk is parked straight into the B-operand layout.
-template <int D, bool DWISE>
+template <int D, bool DWISE, bool BF16>
 __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockArgs a) {
+    constexpr int EB = BF16 ? 2 : 4;                      // bytes of a stored activation
     constexpr int kRbCK = DWISE ? 8 : 16;                 // channels per chunk
     constexpr int NCH = kRbC / kRbCK;
     constexpr int TCP = kRbTC + 2 * D;                    // patch columns
@@ -107,20 +109,20 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
             const int ch = e / PLANE, r = (e % PLANE) / TCP, c = e % TCP;
             const int grow = row0 - (DWISE ? 1 : 0) + r, gcol = col0 - D + c;
             const bool ok = e < NEL && (unsigned)grow < (unsigned)a.H && (unsigned)gcol < (unsigned)a.W;
-            voff[s] = ok ? ((ch * a.H + grow) * a.W + gcol) * 4 : kOob;
+            voff[s] = ok ? ((ch * a.H + grow) * a.W + gcol) * EB : kOob;
         }
     };
     auto fetch = [&](int n, int chunk) {
-        const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * kRbC * HW), 0,
-                                                           kRbC * HW * 4, 0x00020000);
-        const int soff = chunk * kRbCK * HW * 4;
+        const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(static_cast<const char*>(a.x) + (size_t)n * kRbC * HW * EB), 0, kRbC * HW * EB, 0x00020000);
+        const int soff = chunk * kRbCK * HW * EB;
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) stage[s] = rb_load(rs0, voff[s], soff);
+        for (int s = 0; s < NSLOT; ++s) stage[s] = buf_ld_act<BF16>(rs0, voff[s], soff);
         if (a.x2) {
-            const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x2 + (size_t)n * kRbC * HW), 0,
-                                                               kRbC * HW * 4, 0x00020000);
+            const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(static_cast<const char*>(a.x2) + (size_t)n * kRbC * HW * EB), 0, kRbC * HW * EB, 0x00020000);
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s) stage[s] += rb_load(rs1, voff[s], soff);
+            for (int s = 0; s < NSLOT; ++s) stage[s] += buf_ld_act<BF16>(rs1, voff[s], soff);
         }
     };
     auto park = [&]() {
@@ -155,20 +157,21 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ocol = col0 + h * 32 + (lane & 31);
-            obase[h] = (orow < a.H && ocol < a.W) ? ((4 * (lane >> 5)) * HW + orow * a.W + ocol) * 4 : kOob;
+            obase[h] = (orow < a.H && ocol < a.W) ? ((4 * (lane >> 5)) * HW + orow * a.W + ocol) * EB : kOob;
         }
         float res[2][2][16];
         auto fetch_residual = [&]() {
-            const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)n * kRbC * HW), 0,
-                                                                  a.residual ? kRbC * HW * 4 : 0, 0x00020000);
+            const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(static_cast<const char*>(a.x) + (size_t)n * kRbC * HW * EB), 0,
+                a.residual ? kRbC * HW * EB : 0, 0x00020000);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int soff = (t * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4;
-                        res[t][h][r] = rb_load(rs_res, obase[h], soff);
+                        const int soff = (t * 32 + (r & 3) + 8 * (r >> 2)) * HW * EB;
+                        res[t][h][r] = buf_ld_act<BF16>(rs_res, obase[h], soff);
                     }
         };
 
@@ -234,7 +237,8 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
 
         // ---- epilogue: bias, PReLU and BatchNorm affine in the layer's order, optional residual ----
         // buffer stores with 32-bit offsets; lanes outside the image carry an out-of-range offset
-        const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)cur_n * kRbC * HW, 0, kRbC * HW * 4, 0x00020000);
+        const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(a.out) + (size_t)cur_n * kRbC * HW * EB, 0,
+                                                              kRbC * HW * EB, 0x00020000);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
                         v = v >= 0.f ? v : alpha * v;
                     }
                     v += res[t][h][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs_out, obase[h], cou * HW * 4, 0);
+                    buf_st_act<BF16>(v, rs_out, obase[h], cou * HW * EB);
                 }
         if (next < a.ntiles) {
             aim(next, n, row0, col0);
@@ -262,20 +266,25 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
     }
 }
 
-template <int D, bool DWISE>
-static hipError_t launch_resblock(int grid, hipStream_t s, const ResblockArgs& a) {
+template <int D, bool DWISE, bool BF16>
+static hipError_t launch_resblock_t(int grid, hipStream_t s, const ResblockArgs& a) {
     constexpr int kRbCK = DWISE ? 8 : 16;
     constexpr int NSLOT = (kRbCK * (kRbTR + (DWISE ? 2 : 0)) * (kRbTC + 2 * D) + 255) / 256;
     constexpr size_t lds = (size_t)((DWISE ? NSLOT * 256 : 0) + kRbCK * kRbBPitch + kRbC * kRbC + 3 * kRbC) * sizeof(float);
     static bool raised = false;                     // dynamic LDS beyond 64 KB is requested once per kernel
     if (!raised) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_layer_kernel<D, DWISE>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_layer_kernel<D, DWISE, BF16>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((resblock_layer_kernel<D, DWISE>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((resblock_layer_kernel<D, DWISE, BF16>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
+}
+
+template <int D, bool DWISE>
+static hipError_t launch_resblock(int grid, hipStream_t s, const ResblockArgs& a, bool bf16) {
+    return bf16 ? launch_resblock_t<D, DWISE, true>(grid, s, a) : launch_resblock_t<D, DWISE, false>(grid, s, a);
 }
 
 static int fill_tiles(ResblockArgs& a) {
@@ -292,10 +301,10 @@ using namespace unetmi;
 
 extern "C" {
 
-int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const float* x, const float* x2,
+int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const void* x, const void* x2,
                               const float* dw_weight, const float* dw_bias, const float* pw_weight,
                               const float* pw_bias, const float* prelu_alpha, const float* bn_scale,
-                              const float* bn_shift, int residual, float* out, void* stream) {
+                              const float* bn_shift, int residual, void* out, int dtype, void* stream) {
     if (N < 0 || H < 1 || W < 1) return api_fail(UNETMI_E_BAD_DESC, "resblock_layer: bad sizes");
     if (C != kRbC) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: built for 64 channels");
     if ((long long)C * H * W * 4 >= (1ll << 31)) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: sample larger than 2 GiB");
@@ -311,21 +320,22 @@ int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const 
     const int grid = fill_tiles(a);
     if (grid < 0) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: too many tiles");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool bf16 = dtype == UNETMI_DTYPE_BF16;
     hipError_t e;
     switch (dilation_w) {
-        case 1: e = launch_resblock<1, true>(grid, s, a); break;
-        case 2: e = launch_resblock<2, true>(grid, s, a); break;
-        case 4: e = launch_resblock<4, true>(grid, s, a); break;
-        case 8: e = launch_resblock<8, true>(grid, s, a); break;
-        case 16: e = launch_resblock<16, true>(grid, s, a); break;
+        case 1: e = launch_resblock<1, true>(grid, s, a, bf16); break;
+        case 2: e = launch_resblock<2, true>(grid, s, a, bf16); break;
+        case 4: e = launch_resblock<4, true>(grid, s, a, bf16); break;
+        case 8: e = launch_resblock<8, true>(grid, s, a, bf16); break;
+        case 16: e = launch_resblock<16, true>(grid, s, a, bf16); break;
         default: return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: time dilation must be 1, 2, 4, 8 or 16");
     }
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("resblock_layer launch: ") + hipGetErrorString(e));
 }
 
-int unetmi_pwconv64_fwd(int N, int H, int W, const float* x, const float* x2, const float* weight, const float* bias,
+int unetmi_pwconv64_fwd(int N, int H, int W, const void* x, const void* x2, const float* weight, const float* bias,
                         const float* scale, const float* shift, const float* leaky_slope, int act_first, int residual,
-                        float* out, void* stream) {
+                        void* out, int dtype, void* stream) {
     if (N < 0 || H < 1 || W < 1) return api_fail(UNETMI_E_BAD_DESC, "pwconv64: bad sizes");
     if ((long long)kRbC * H * W * 4 >= (1ll << 31)) return api_fail(UNETMI_E_UNSUPPORTED, "pwconv64: sample larger than 2 GiB");
     if (N == 0) return UNETMI_OK;
@@ -337,7 +347,7 @@ int unetmi_pwconv64_fwd(int N, int H, int W, const float* x, const float* x2, co
     a.out = out; a.N = N; a.H = H; a.W = W; a.residual = residual ? 1 : 0; a.act_first = act_first ? 1 : 0;
     const int grid = fill_tiles(a);
     if (grid < 0) return api_fail(UNETMI_E_UNSUPPORTED, "pwconv64: too many tiles");
-    const hipError_t e = launch_resblock<0, false>(grid, static_cast<hipStream_t>(stream), a);
+    const hipError_t e = launch_resblock<0, false>(grid, static_cast<hipStream_t>(stream), a, dtype == UNETMI_DTYPE_BF16);
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("pwconv64 launch: ") + hipGetErrorString(e));
 }
 

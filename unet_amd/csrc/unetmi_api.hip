@@ -110,6 +110,11 @@ int unetmi_conv2d_fwd(const UnetmiConvDesc* d, const float* in0, const float* in
     if ((d->has_residual != 0) != (residual != nullptr))
         return fail(UNETMI_E_BAD_ARG, "residual pointer vs has_residual");
     if (pl.lds_bytes_dma > 80 * 1024) return fail(UNETMI_E_UNSUPPORTED, "LDS images exceed 80 KB");
+    if (d->reserved[0] != UNETMI_DTYPE_F32 && d->reserved[0] != UNETMI_DTYPE_BF16)
+        return fail(UNETMI_E_BAD_DESC, "unknown activation storage type in reserved[0]");
+    if (!pl.direct && pl.NG == 2 && d->reserved[0] == UNETMI_DTYPE_BF16)
+        return fail(UNETMI_E_UNSUPPORTED,
+                    "bfloat16 storage on a time-stride-2 transposed conv is not built: widen the operands");
     if (!pl.direct && pl.NG == 2 && needs_two_loads(*d, pl))
         return fail(UNETMI_E_UNSUPPORTED,
                     "summed two-source input on a time-stride-2 transposed conv: add the inputs first");

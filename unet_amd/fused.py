@@ -52,8 +52,8 @@ def require_device_tensor(x, who):
         raise RuntimeError(
             "{}: the forward runs only on an MI355X device tensor (got {}); this package has no "
             "CPU path".format(who, "a CPU tensor" if isinstance(x, torch.Tensor) else type(x)))
-    if x.dtype != torch.float32:
-        raise RuntimeError("{}: expected float32 input, got {}".format(who, x.dtype))
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("{}: expected a float32 (or bfloat16-storage) input, got {}".format(who, x.dtype))
 
 
 class FusedConv:
@@ -124,7 +124,7 @@ class FusedConv:
             weight = c.weight.permute(0, 1, 3, 2) if self.swap_hw else c.weight
             wpacked = pack_conv_weights(weight, c.in_channels, 0, geom,
                                         [transposed, _lib.IN_SINGLE, code, 0]).to(device)
-            self._weight_for_split, self._split_images = weight.detach(), {}
+            self._weight_for_split, self._split_images = weight.detach().to(torch.float32).contiguous(), {}
             f32 = dict(dtype=torch.float32, device=device)
             bias = (c.bias.detach().to(**f32) if c.bias is not None else torch.zeros(K, **f32)).contiguous()
             n = self.norm
@@ -194,8 +194,14 @@ class FusedConv:
                                   st["act_param"], gate, residual, st["geom"],
                                   [st["transposed"], mode, st["act"], int(self.act_first)])
             except _lib.UnetmiError as e:
-                if e.code != _lib.E_UNSUPPORTED or x2 is None:
+                if e.code != _lib.E_UNSUPPORTED or (x2 is None and x.dtype == torch.float32):
                     raise
+            if x.dtype != torch.float32:
+                # a layer shape the bfloat16-storage kernels do not cover (time-stride-2 transposed
+                # convolutions): widen the operands, run the fp32 kernel, round the result
+                wide = self(x.float(), None if x2 is None else x2.float(), in_mode=in_mode, gate=gate,
+                            residual=None if residual is None else residual.float())
+                return wide.to(x.dtype)
             # the one case the kernels do not take two sources for (a summed input on a
             # time-stride-2 transposed conv): form the combined input, run the single-source kernel
             merged = torch.cat([x, x2], dim=1) if mode == _lib.IN_CONCAT else x + x2

@@ -51,9 +51,9 @@ def lstm_forward(lstm, x, cache):
         seq[:, :, :B] = x.permute(1, 2, 0)
         sync = torch.empty(lstm.hidden_size // 4 + 1, dtype=torch.int32, device=dev)
         for layer in range(lstm.num_layers):
-            w_ih = getattr(lstm, "weight_ih_l{}".format(layer)).detach()
-            w_hr = getattr(lstm, "weight_hr_l{}".format(layer)).detach()
-            bias = (getattr(lstm, "bias_ih_l{}".format(layer)) + getattr(lstm, "bias_hh_l{}".format(layer))).detach()
+            w_ih = getattr(lstm, "weight_ih_l{}".format(layer)).detach().float()
+            w_hr = getattr(lstm, "weight_hr_l{}".format(layer)).detach().float()
+            bias = (getattr(lstm, "bias_ih_l{}".format(layer)).float() + getattr(lstm, "bias_hh_l{}".format(layer)).float()).detach()
             gx = torch.matmul(w_ih, seq) + bias[None, :, None]                        # [T, 4H, BP]
             wrec = _folded_recurrent_matrix(lstm, layer, cache)
             hfull = torch.empty((T + 1, H, BP), dtype=torch.float32, device=dev)

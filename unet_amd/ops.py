@@ -28,7 +28,16 @@ def conv_out_size(size, k, s, p, d, op, transposed):
     return (size + 2 * p - d * (k - 1) - 1) // s + 1
 
 
-def make_desc(N, C0, C1, H, W, geom, flags, act_pc=0, has_gate=0, has_residual=0):
+def dtype_code(t):
+    """UNETMI_DTYPE_* of an activation tensor (fp32 or bfloat16 storage)."""
+    if t.dtype == torch.float32:
+        return _lib.DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.DTYPE_BF16
+    raise ValueError("activations must be float32 or bfloat16, got {}".format(t.dtype))
+
+
+def make_desc(N, C0, C1, H, W, geom, flags, act_pc=0, has_gate=0, has_residual=0, dtype=0):
     K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
     transposed, in_mode, act, act_first = flags
     d = ConvDesc()
@@ -38,6 +47,7 @@ def make_desc(N, C0, C1, H, W, geom, flags, act_pc=0, has_gate=0, has_residual=0
     d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw, d.oph, d.opw = kh, kw, sh, sw, ph, pw, dh, dw, oph, opw
     d.transposed, d.in_mode, d.act, d.act_first = transposed, in_mode, act, act_first
     d.act_param_per_channel, d.has_gate, d.has_residual = act_pc, has_gate, has_residual
+    d.reserved[0] = dtype
     return d
 
 
@@ -76,37 +86,38 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _need(t, name, shape=None):
-    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
-        raise ValueError("unetmi::conv2d_fwd: {} must be a contiguous fp32 device tensor".format(name))
+def _need(t, name, shape=None, dtype=torch.float32):
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError("unetmi::conv2d_fwd: {} must be a contiguous {} device tensor".format(name, dtype))
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise ValueError("unetmi::conv2d_fwd: {} has shape {}, expected {}".format(
             name, tuple(t.shape), tuple(shape)))
 
 
 def _conv2d_fwd_cuda(in0, in1, wpacked, bias, scale, shift, act_param, gate, residual, geom, flags):
-    _need(in0, "in0")
+    code = dtype_code(in0)
+    _need(in0, "in0", dtype=in0.dtype)
     N, C0, H, W = in0.shape
     C1 = 0
     if in1 is not None:
-        _need(in1, "in1")
+        _need(in1, "in1", dtype=in0.dtype)
         if in1.shape[0] != N or tuple(in1.shape[2:]) != (H, W):
             raise ValueError("unetmi::conv2d_fwd: in1 {} does not match in0 {}".format(
                 tuple(in1.shape), tuple(in0.shape)))
         C1 = in1.shape[1]
     K = geom[0]
     act_pc = 1 if (act_param is not None and act_param.numel() > 1) else 0
-    d = make_desc(N, C0, C1, H, W, geom, flags, act_pc, int(gate is not None), int(residual is not None))
+    d = make_desc(N, C0, C1, H, W, geom, flags, act_pc, int(gate is not None), int(residual is not None), code)
     for t, name in ((bias, "bias"), (scale, "scale"), (shift, "shift")):
         _need(t, name, (K,))
     _need(wpacked, "wpacked")
     if act_param is not None:
         _need(act_param, "act_param", (K,) if act_pc else (1,))
-    out = torch.empty((N, K, d.OH, d.OW), dtype=torch.float32, device=in0.device)
+    out = torch.empty((N, K, d.OH, d.OW), dtype=in0.dtype, device=in0.device)
     if gate is not None:
         _need(gate, "gate", (N, K))
     if residual is not None:
-        _need(residual, "residual", out.shape)
+        _need(residual, "residual", out.shape, dtype=in0.dtype)
     expect = _lib.lib.unetmi_conv2d_packed_weight_bytes(ctypes.byref(d))
     if expect == 0:
         raise _lib.UnetmiError("unetmi::conv2d_fwd: " + _lib.last_error())
@@ -156,9 +167,9 @@ _LIBRARY.define("resblock_layer(Tensor x, Tensor? x2, Tensor dw_weight, Tensor? 
                 "Tensor? pw_bias, Tensor alpha, Tensor scale, Tensor shift, int dilation, bool residual) -> Tensor")
 
 
-def _dev(t, name, op):
-    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
-        raise ValueError("unetmi::{}: {} must be a contiguous fp32 device tensor".format(op, name))
+def _dev(t, name, op, dtype=torch.float32):
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError("unetmi::{}: {} must be a contiguous {} device tensor".format(op, name, dtype))
 
 
 def _stream(t):
@@ -166,40 +177,43 @@ def _stream(t):
 
 
 def _dwconv2d_fwd_cuda(x, x2, weight, bias, padding, dilation):
-    _dev(x, "x", "dwconv2d_fwd"), _dev(weight, "weight", "dwconv2d_fwd")
+    code = dtype_code(x)
+    _dev(x, "x", "dwconv2d_fwd", x.dtype), _dev(weight, "weight", "dwconv2d_fwd")
     N, C, H, W = x.shape
     if tuple(weight.shape[:2]) != (C, 1):
         raise ValueError("unetmi::dwconv2d_fwd: weight must be [C,1,kh,kw]")
     if x2 is not None:
-        _dev(x2, "x2", "dwconv2d_fwd")
+        _dev(x2, "x2", "dwconv2d_fwd", x.dtype)
         if x2.shape != x.shape:
             raise ValueError("unetmi::dwconv2d_fwd: x2 shape differs from x")
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
         check(_lib.lib.unetmi_dwconv2d_fwd(N, C, H, W, weight.shape[2], weight.shape[3], padding[0], padding[1],
                                            dilation[0], dilation[1], _ptr(x), _ptr(x2), _ptr(weight), _ptr(bias),
-                                           _ptr(out), _stream(x)), "unetmi_dwconv2d_fwd")
+                                           _ptr(out), code, _stream(x)), "unetmi_dwconv2d_fwd")
     return out
 
 
 def _layernorm_f_cuda(x, gamma, beta, eps, out, c_off):
-    _dev(x, "x", "layernorm_f"), _dev(out, "out", "layernorm_f")
+    code = dtype_code(x)
+    _dev(x, "x", "layernorm_f", x.dtype), _dev(out, "out", "layernorm_f", x.dtype)
     N, C, F, T = x.shape
     if out.shape[0] != N or tuple(out.shape[2:]) != (F, T) or gamma.numel() != F or beta.numel() != F:
         raise ValueError("unetmi::layernorm_f: shape mismatch")
     with torch.cuda.device(x.device):
         check(_lib.lib.unetmi_layernorm_f_fwd(N, C, F, T, out.shape[1], c_off, eps, _ptr(x), _ptr(gamma), _ptr(beta),
-                                              _ptr(out), _stream(x)), "unetmi_layernorm_f_fwd")
+                                              _ptr(out), code, _stream(x)), "unetmi_layernorm_f_fwd")
 
 
 def _tanh_mask_mul_cuda(y, x, eps):
-    _dev(y, "y", "tanh_mask_mul"), _dev(x, "x", "tanh_mask_mul")
+    code = dtype_code(y)
+    _dev(y, "y", "tanh_mask_mul", y.dtype), _dev(x, "x", "tanh_mask_mul", y.dtype)
     N, K, F, T = y.shape
     if x.shape[0] != N or x.shape[1] < K or tuple(x.shape[2:]) != (F, T):
         raise ValueError("unetmi::tanh_mask_mul: x must be [N, >=K, F, T]")
     out = torch.empty_like(y)
     with torch.cuda.device(y.device):
-        check(_lib.lib.unetmi_tanh_mask_mul(N, K, x.shape[1], F, T, eps, _ptr(y), _ptr(x), _ptr(out), _stream(y)),
+        check(_lib.lib.unetmi_tanh_mask_mul(N, K, x.shape[1], F, T, eps, _ptr(y), _ptr(x), _ptr(out), code, _stream(y)),
               "unetmi_tanh_mask_mul")
     return out
 
@@ -221,7 +235,8 @@ def _crf_apply_cuda(H, X):
 
 
 def _resblock_layer_cuda(x, x2, dw_weight, dw_bias, pw_weight, pw_bias, alpha, scale, shift, dilation, residual):
-    _dev(x, "x", "resblock_layer")
+    code = dtype_code(x)
+    _dev(x, "x", "resblock_layer", x.dtype)
     N, C, H, W = x.shape
     for t, name, numel in ((dw_weight, "dw_weight", C * 9), (pw_weight, "pw_weight", C * C), (alpha, "alpha", 1),
                            (scale, "scale", C), (shift, "shift", C)):
@@ -229,32 +244,33 @@ def _resblock_layer_cuda(x, x2, dw_weight, dw_bias, pw_weight, pw_bias, alpha, s
         if t.numel() != numel:
             raise ValueError("unetmi::resblock_layer: {} has {} elements, expected {}".format(name, t.numel(), numel))
     if x2 is not None:
-        _dev(x2, "x2", "resblock_layer")
+        _dev(x2, "x2", "resblock_layer", x.dtype)
         if x2.shape != x.shape:
             raise ValueError("unetmi::resblock_layer: x2 shape differs from x")
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
         check(_lib.lib.unetmi_resblock_layer_fwd(N, C, H, W, dilation, _ptr(x), _ptr(x2), _ptr(dw_weight), _ptr(dw_bias),
                                                  _ptr(pw_weight), _ptr(pw_bias), _ptr(alpha), _ptr(scale), _ptr(shift),
-                                                 int(residual), _ptr(out), _stream(x)), "unetmi_resblock_layer_fwd")
+                                                 int(residual), _ptr(out), code, _stream(x)), "unetmi_resblock_layer_fwd")
     return out
 
 
 def _pwconv64_cuda(x, x2, weight, bias, scale, shift, slope, act_first, residual):
-    _dev(x, "x", "pwconv64")
+    code = dtype_code(x)
+    _dev(x, "x", "pwconv64", x.dtype)
     N, C, H, W = x.shape
     if C != 64 or weight.numel() != 64 * 64:
         raise ValueError("unetmi::pwconv64: built for 64 -> 64 channels")
     for t, name in ((weight, "weight"), (scale, "scale"), (shift, "shift")):
         _dev(t, name, "pwconv64")
     if x2 is not None:
-        _dev(x2, "x2", "pwconv64")
+        _dev(x2, "x2", "pwconv64", x.dtype)
         if x2.shape != x.shape:
             raise ValueError("unetmi::pwconv64: x2 shape differs from x")
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
         check(_lib.lib.unetmi_pwconv64_fwd(N, H, W, _ptr(x), _ptr(x2), _ptr(weight), _ptr(bias), _ptr(scale), _ptr(shift),
-                                           _ptr(slope), int(act_first), int(residual), _ptr(out), _stream(x)),
+                                           _ptr(slope), int(act_first), int(residual), _ptr(out), code, _stream(x)),
               "unetmi_pwconv64_fwd")
     return out
 

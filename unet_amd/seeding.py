@@ -9,6 +9,7 @@ folding them into a kernel epilogue is actually exercised.
 """
 
 import math
+import re
 
 import numpy as np
 import torch
@@ -64,7 +65,11 @@ def seeded_fill_(module, seed=0):
     the number of products summed into one output element (for a transposed
     conv the taps that actually hit one output: C_in*kH*kW / (sH*sW)), which
     keeps activations O(1) through 20 layers.  Norm layers: weight U(0.5, 1.5),
-    bias and running_mean U(-0.2, 0.2), running_var U(0.5, 1.5).  PReLU slope
+    bias and running_mean U(-0.2, 0.2), running_var U(0.5, 1.5); the BatchNorm that
+    closes a residual-block layer (``res_<i>.3``) gets a quarter of that weight range,
+    because a block sums five such layers onto its running value and twelve blocks in a
+    row would otherwise grow the activations by ~4x each (saturating ResUNet's tanh
+    mask completely, which would leave a parity test nothing but signs to compare).  PReLU slope
     U(0.1, 0.4).  LSTM: U(-k, k), k = 1/sqrt(hidden).
     Shared tensors (one PReLU registered under several names) are written once.
     """
@@ -101,7 +106,8 @@ def seeded_fill_(module, seed=0):
                 put(m.bias, mname + ".bias", -0.1, 0.1)
         elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d, nn.InstanceNorm2d, nn.LayerNorm)):
             if getattr(m, "weight", None) is not None:
-                put(m.weight, mname + ".weight", 0.5, 1.5)
+                g = 0.25 if re.search(r"(^|\.)res_\d+\.3$", mname) else 1.0
+                put(m.weight, mname + ".weight", 0.5 * g, 1.5 * g)
                 put(m.bias, mname + ".bias", -0.2, 0.2)
             if getattr(m, "running_mean", None) is not None:
                 put(m.running_mean, mname + ".running_mean", -0.2, 0.2)
