@@ -146,8 +146,12 @@ def run_train(args, rank, world, dev):
     x = synthetic_batch(TRAIN_PER_GPU_BATCH, 1234 + rank).to(dev)
     target = torch.rand((TRAIN_PER_GPU_BATCH, 1, F_BINS, T_PADDED),
                         generator=torch.Generator().manual_seed(99 + rank)).to(dev)
-    for _ in range(args.warmup):
+    verbose = os.environ.get("UNETMI_BENCH_VERBOSE") == "1"
+    for i in range(args.warmup):
         loss = train_step(net, opt, x, target)
+        if verbose:
+            torch.cuda.synchronize()
+            print("[rank {}] warm-up step {} loss {:.5f}".format(rank, i, loss.item()), file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -203,11 +207,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus {} but WORLD_SIZE={}: launch with torch.distributed.run "
                          "--nproc-per-node {}".format(args.gpus, world, args.gpus))
+    # Rehearsal knobs for a box with fewer GPUs than ranks (never used by a real run): all ranks on
+    # device 0 and the gloo backend instead of RCCL, which refuses two ranks on one GPU.
+    rehearsal = os.environ.get("UNETMI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.mode == "train":
         run_train(args, rank, world, dev)
