@@ -333,7 +333,14 @@ class FlatBucket:
         size, by which the caller divides (FlatAdam.step folds the division into the update)."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.grad, group=group)
+            if dist.get_backend(group) == "gloo" and self.grad.is_cuda:
+                # gloo stages device tensors through the host on its own streams; do the staging here,
+                # synchronously, so the exchange cannot interleave with this process's queued kernels
+                host = self.grad.cpu()
+                dist.all_reduce(host, group=group)
+                self.grad.copy_(host)
+            else:
+                dist.all_reduce(self.grad, group=group)
             return dist.get_world_size(group)
         return 1
 
