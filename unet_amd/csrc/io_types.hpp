@@ -42,6 +42,33 @@ __device__ __forceinline__ void buf_st_act(float v, __amdgpu_buffer_rsrc_t rs, i
     else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, 0);
 }
 
+// four consecutive activations per lane: one 16-byte (fp32) or 8-byte (bf16) access; needs only element alignment
+typedef float io_f32x4 __attribute__((ext_vector_type(4)));
+typedef int io_i32x4 __attribute__((ext_vector_type(4)));
+typedef int io_i32x2 __attribute__((ext_vector_type(2)));
+
+template <bool BF16>
+__device__ __forceinline__ io_f32x4 buf_ld_act4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    if (BF16) {
+        const io_i32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        return io_f32x4{__builtin_bit_cast(float, (unsigned)w[0] << 16), __builtin_bit_cast(float, (unsigned)w[0] & 0xffff0000u),
+                        __builtin_bit_cast(float, (unsigned)w[1] << 16), __builtin_bit_cast(float, (unsigned)w[1] & 0xffff0000u)};
+    }
+    return __builtin_bit_cast(io_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+
+template <bool BF16>
+__device__ __forceinline__ void buf_st_act4(io_f32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    if (BF16) {
+        io_i32x2 w;
+        w[0] = (int)((unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16));
+        w[1] = (int)((unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16));
+        __builtin_amdgcn_raw_buffer_store_b64(w, rs, voff, soff, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(io_i32x4, v), rs, voff, soff, 0);
+    }
+}
+
 template <bool BF16> constexpr int act_bytes() { return BF16 ? 2 : 4; }
 
 }  // namespace unetmi

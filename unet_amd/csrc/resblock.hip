@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <type_traits>
 
@@ -30,12 +31,10 @@ namespace unetmi {
 int api_fail(int code, const std::string& msg);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRbC = 64;        // channels
 constexpr int kRbTR = 4;        // tile rows
-constexpr int kRbTC = 64;       // tile columns
-constexpr int kRbBPitch = 288;  // pitch of a channel row of the B operand (256 pixels + 32: the two
-                                // lane halves of an MFMA read land in different banks)
 
 struct ResblockArgs {
     const void* x;
@@ -50,6 +49,7 @@ struct ResblockArgs {
     void* out;
     int N, H, W, residual, act_first;
     int tiles_h, tiles_w, ntiles;
+    int ablate;             // developer probe (environment UNETMI_RB_ABLATE): bit mask of stages to skip
 };
 
 __device__ __forceinline__ float rb_load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
@@ -58,8 +58,16 @@ __device__ __forceinline__ float rb_load(__amdgpu_buffer_rsrc_t rs, int voff, in
 
 // DWISE = false drops the depthwise stage: a plain 64 -> 64 pointwise convolution (D = 0, no halo),
 // whose input chunk is parked straight into the B-operand layout.
-template <int D, bool DWISE, bool BF16>
-__global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockArgs a) {
+// TC = tile columns (64 or 32).  The narrower tile halves the accumulators (32 registers), which lets four
+// workgroups share a compute unit instead of two: the layer is a chain of short phases (fetch, depthwise,
+// MFMA, store) and more resident waves hide each other's latencies.
+template <int D, bool DWISE, bool BF16, int TC>
+__global__ __launch_bounds__(256, TC == 32 ? 4 : 2) void resblock_layer_kernel(const ResblockArgs a) {
+    constexpr int kRbTC = TC;
+    constexpr int NH = TC / 32;                           // 32-pixel MFMA tiles per wave (one image row of the tile)
+    constexpr int kRbBPitch = kRbTR * TC + 32;            // B-operand row pitch: the two lane halves of an MFMA read
+                                                          // (channels 2k, 2k+1) land in different banks
+    constexpr int DG = 256 / TC;                          // depthwise thread groups (each takes CK/DG channels)
     constexpr int EB = BF16 ? 2 : 4;                      // bytes of a stored activation
     constexpr int kRbCK = DWISE ? 8 : 16;                 // channels per chunk
     constexpr int NCH = kRbC / kRbCK;
@@ -74,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
     float* s_b = smem + (DWISE ? NSLOT * 256 : 0);        // [chunk][kRbBPitch] B operand of the pointwise product
     float* s_w = s_b + kRbCK * kRbBPitch;                 // [32 k-steps][2 tiles][64 lanes] A operands
     float* s_par = s_w + kRbC * kRbC;                     // [3][64] pointwise bias, BatchNorm scale, shift
+    float* s_dw = s_par + 3 * kRbC;                       // [64][10] depthwise taps + bias
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: lets per-channel constants be scalar loads
@@ -90,10 +99,16 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
         s_par[kRbC + tid] = a.scale[tid];
         s_par[2 * kRbC + tid] = a.shift[tid];
     }
+    if (DWISE) {
+        for (int i = tid; i < kRbC * 10; i += 256) {
+            const int ch = i / 10, k = i - ch * 10;
+            s_dw[i] = k < 9 ? a.dw_w[ch * 9 + k] : (a.dw_b ? a.dw_b[ch] : 0.f);
+        }
+    }
     const float alpha = a.alpha ? a.alpha[0] : 1.f;
 
     // depthwise work of this thread: column dcol of the tile, a quarter of the chunk's channels
-    const int dcol = tid & 63, dch0 = wave * (kRbCK / 4);
+    const int dcol = tid % TC, dch0 = (tid / TC) * (kRbCK / DG);
 
     int voff[NSLOT];
     float stage[NSLOT];
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
             const_cast<char*>(static_cast<const char*>(a.x) + (size_t)n * kRbC * HW * EB), 0, kRbC * HW * EB, 0x00020000);
         const int soff = chunk * kRbCK * HW * EB;
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) stage[s] = buf_ld_act<BF16>(rs0, voff[s], soff);
+        for (int s = 0; s < NSLOT; ++s) stage[s] = (a.ablate & 16) ? 0.f : buf_ld_act<BF16>(rs0, voff[s], soff);
         if (a.x2) {
             const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(static_cast<const char*>(a.x2) + (size_t)n * kRbC * HW * EB), 0, kRbC * HW * EB, 0x00020000);
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
         for (int s = 0; s < NSLOT; ++s) {
             const int e = s * 256 + tid;
             if (DWISE) s_in[e] = stage[s];
-            else s_b[(e >> 8) * kRbBPitch + (e & 255)] = stage[s];      // PLANE = 256: [channel][pixel]
+            else s_b[(e / PLANE) * kRbBPitch + (e % PLANE)] = stage[s];   // PLANE = tile pixels: [channel][pixel]
         }
     };
 
@@ -143,36 +158,37 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
         park();
         __syncthreads();
 
-        f32x16 acc[2][2];              // [output-channel tile][pixel tile of this wave's row]
+        f32x16 acc[2][NH];             // [output-channel tile][pixel tile of this wave's row]
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][h][r] = 0.f;
 
-        // residual values of this wave's outputs, fetched while the last chunk computes
+        // residual values of this wave's outputs, fetched while the last chunk computes.  Output mapping
+        // (channels are the MFMA rows, pixels its columns): lane l holds pixel h*32 + (l&31) of image row
+        // `orow`, register r channel t*32 + (r&3) + 8*(r>>2) + 4*(l>>5); a store instruction writes two
+        // contiguous 128-byte runs, which measured faster than 16 bytes per lane scattered over 64 channels.
         const int orow = row0 + wave;
-        int obase[2];
+        int obase[NH];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             const int ocol = col0 + h * 32 + (lane & 31);
             obase[h] = (orow < a.H && ocol < a.W) ? ((4 * (lane >> 5)) * HW + orow * a.W + ocol) * EB : kOob;
         }
-        float res[2][2][16];
+        float res[2][NH][16];
         auto fetch_residual = [&]() {
             const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(static_cast<const char*>(a.x) + (size_t)n * kRbC * HW * EB), 0,
-                a.residual ? kRbC * HW * EB : 0, 0x00020000);
+                (a.residual && !(a.ablate & 2)) ? kRbC * HW * EB : 0, 0x00020000);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NH; ++h)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int soff = (t * 32 + (r & 3) + 8 * (r >> 2)) * HW * EB;
-                        res[t][h][r] = buf_ld_act<BF16>(rs_res, obase[h], soff);
-                    }
+                    for (int r = 0; r < 16; ++r)
+                        res[t][h][r] = buf_ld_act<BF16>(rs_res, obase[h], (t * 32 + (r & 3) + 8 * (r >> 2)) * HW * EB);
         };
 
         // one chunk: start the next fetch (or, on the last chunk, the residual loads), depthwise stage,
@@ -182,15 +198,15 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
             constexpr bool LAST = decltype(last_tag)::value;
             if (!LAST) fetch(n, chunk + 1);
             else fetch_residual();
-            if (DWISE) {
+            if (DWISE && !(a.ablate & 4)) {
                 // ---- depthwise 3x3, dilation (1, D) ---- (one channel at a time: keeps the live set small)
 #pragma nounroll
-                for (int cc = 0; cc < kRbCK / 4; ++cc) {
+                for (int cc = 0; cc < kRbCK / DG; ++cc) {
                     const int chl = dch0 + cc, chg = chunk * kRbCK + chl;
                     float k[9];
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) k[i] = a.dw_w[chg * 9 + i];
-                    const float b = a.dw_b ? a.dw_b[chg] : 0.f;
+                    for (int i = 0; i < 9; ++i) k[i] = s_dw[chg * 10 + i];
+                    const float b = s_dw[chg * 10 + 9];
                     float v[PROWS][3];
 #pragma unroll
                     for (int r = 0; r < PROWS; ++r)
@@ -209,18 +225,19 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
                 __syncthreads();
             }
             // ---- pointwise product over this chunk's input channels ----
+            if (!(a.ablate & 8))
 #pragma unroll
             for (int ks = 0; ks < kRbCK / 2; ++ks) {
                 const int gks = chunk * (kRbCK / 2) + ks;
-                float bv[2];
+                float bv[NH];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NH; ++h)
                     bv[h] = s_b[(2 * ks + (lane >> 5)) * kRbBPitch + wave * kRbTC + h * 32 + (lane & 31)];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const float av = s_w[(gks * 2 + t) * 64 + lane];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < NH; ++h)
                         acc[t][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[h], acc[t][h], 0, 0, 0);
                 }
             }
@@ -242,22 +259,24 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                const int cou = t * 32 + (r & 3) + 8 * (r >> 2);            // + 4*(lane>>5), folded into obase
+                const int co = cou + 4 * (lane >> 5);
+                const float pb = s_par[co], sc = s_par[kRbC + co], sh = s_par[2 * kRbC + co];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cou = t * 32 + (r & 3) + 8 * (r >> 2);            // + 4*(lane>>5), folded into obase
-                    const int co = cou + 4 * (lane >> 5);
-                    float v = acc[t][h][r] + s_par[co];
+                for (int h = 0; h < NH; ++h) {
+                    float v = acc[t][h][r] + pb;
                     if (a.act_first) {
                         v = v >= 0.f ? v : alpha * v;
-                        v = fmaf(v, s_par[kRbC + co], s_par[2 * kRbC + co]);
+                        v = fmaf(v, sc, sh);
                     } else {
-                        v = fmaf(v, s_par[kRbC + co], s_par[2 * kRbC + co]);
+                        v = fmaf(v, sc, sh);
                         v = v >= 0.f ? v : alpha * v;
                     }
                     v += res[t][h][r];
-                    buf_st_act<BF16>(v, rs_out, obase[h], cou * HW * EB);
+                    if (!(a.ablate & 1) || v == 123.456f) buf_st_act<BF16>(v, rs_out, obase[h], cou * HW * EB);
                 }
+            }
         if (next < a.ntiles) {
             aim(next, n, row0, col0);
             fetch(n, 0);
@@ -266,33 +285,38 @@ __global__ __launch_bounds__(256, 2) void resblock_layer_kernel(const ResblockAr
     }
 }
 
-template <int D, bool DWISE, bool BF16>
+template <int D, bool DWISE, bool BF16, int TC>
 static hipError_t launch_resblock_t(int grid, hipStream_t s, const ResblockArgs& a) {
     constexpr int kRbCK = DWISE ? 8 : 16;
-    constexpr int NSLOT = (kRbCK * (kRbTR + (DWISE ? 2 : 0)) * (kRbTC + 2 * D) + 255) / 256;
-    constexpr size_t lds = (size_t)((DWISE ? NSLOT * 256 : 0) + kRbCK * kRbBPitch + kRbC * kRbC + 3 * kRbC) * sizeof(float);
+    constexpr int NSLOT = (kRbCK * (kRbTR + (DWISE ? 2 : 0)) * (TC + 2 * D) + 255) / 256;
+    constexpr size_t lds = (size_t)((DWISE ? NSLOT * 256 : 0) + kRbCK * (kRbTR * TC + 32) + kRbC * kRbC + 3 * kRbC + 10 * kRbC) * sizeof(float);
     static bool raised = false;                     // dynamic LDS beyond 64 KB is requested once per kernel
     if (!raised) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_layer_kernel<D, DWISE, BF16>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_layer_kernel<D, DWISE, BF16, TC>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((resblock_layer_kernel<D, DWISE, BF16>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((resblock_layer_kernel<D, DWISE, BF16, TC>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
+constexpr int kRbTileCols = 32;     // see the kernel's TC
+
 template <int D, bool DWISE>
 static hipError_t launch_resblock(int grid, hipStream_t s, const ResblockArgs& a, bool bf16) {
-    return bf16 ? launch_resblock_t<D, DWISE, true>(grid, s, a) : launch_resblock_t<D, DWISE, false>(grid, s, a);
+    return bf16 ? launch_resblock_t<D, DWISE, true, kRbTileCols>(grid, s, a)
+                : launch_resblock_t<D, DWISE, false, kRbTileCols>(grid, s, a);
 }
 
 static int fill_tiles(ResblockArgs& a) {
-    a.tiles_h = (a.H + kRbTR - 1) / kRbTR; a.tiles_w = (a.W + kRbTC - 1) / kRbTC;
+    const char* ab = std::getenv("UNETMI_RB_ABLATE");
+    a.ablate = ab ? std::atoi(ab) : 0;
+    a.tiles_h = (a.H + kRbTR - 1) / kRbTR; a.tiles_w = (a.W + kRbTileCols - 1) / kRbTileCols;
     const long long nt = (long long)a.N * a.tiles_h * a.tiles_w;
     if (nt > 0x7fffffffll) return -1;
     a.ntiles = (int)nt;
-    return (int)std::min<long long>(nt, 256 * 2 * 4);       // persistent: a few tiles per workgroup
+    return (int)std::min<long long>(nt, 256 * 4 * 4);       // persistent: a few tiles per workgroup
 }
 
 }  // namespace unetmi
