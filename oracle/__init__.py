@@ -20,10 +20,11 @@ from .blocks import (Encoder, Decoder, ResBlock, DSEncoder, DSDecoder, Attractor
 from .nets import UNet, UNet20, ResUNet, DSUNet
 from .tables import unet20_layers, default_unet, dsunet_architecture
 from .masking import crf_apply, resunet_mask_apply, crm_apply
+from .helper import DSUNet_helper
 
 __all__ = [
     "Encoder", "Decoder", "ResBlock", "DSEncoder", "DSDecoder", "Attractor",
     "AttractEncoder", "CRM", "UNet", "UNet20", "ResUNet", "DSUNet",
     "unet20_layers", "default_unet", "dsunet_architecture",
-    "crf_apply", "resunet_mask_apply", "crm_apply",
+    "crf_apply", "resunet_mask_apply", "crm_apply", "DSUNet_helper",
 ]

@@ -250,6 +250,25 @@ def main():
         save("dsunet_eval", out=torch.view_as_real(y_ref).numpy(),
              masked=torch.view_as_real(ref.masking(X, y_ref)).numpy())
 
+    # ---------------------------------------------------------------- DSUNet_helper (wave in, wave out)
+    print("DSUNet_helper (STFT -> features -> DSUNet -> CRM -> iSTFT), B=2 C=4 L=4000")
+    ref = R_ds.DSUNet_helper(arch)
+    seeded_fill_(ref, seed=51)
+    mine = oracle.DSUNet_helper(arch)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    assert sorted(ref.state_dict().keys()) == sorted(mine.state_dict().keys())
+    wav = normal("helper/x", (2, 4, 4000), seed=51) * 0.1
+    angle = uniform("helper/angle", (2,), 0.0, 360.0, seed=51)
+    mic = uniform("helper/mic", (2, 4, 3), -0.05, 0.05, seed=51)
+    ref.eval(), mine.eval()
+    with torch.no_grad():
+        y_ref, y_mine = ref(wav, angle, mic), mine(wav, angle, mic)
+        require_equal(ref.steering_vector(angle, mic), mine.steering_vector(angle, mic), "steering vector")
+    require_equal(y_ref, y_mine, "DSUNet_helper eval")
+    assert tuple(y_ref.shape) == (2, 4000)
+    if out is not None:
+        save("dsunet_helper_eval", out=y_ref.numpy())
+
     # ------------------------------------------------- negative behaviours (kept as facts)
     print("negative behaviours of the reference")
     facts = {}

@@ -262,3 +262,46 @@ def test_conv_bf16_storage(device, geom):
     assert got.dtype == torch.bfloat16
     # one rounding of the output to bf16: 2^-9 relative per element
     assert_close(got.float(), want, tol=6e-3, what="bf16 conv")
+
+
+@pytest.mark.parametrize("L", [4000, 1280, 777])
+def test_device_stft_and_istft_match_torch(device, L):
+    """The convolution-kernel STFT / inverse STFT against torch.stft / torch.istft on the CPU
+    (the calls the reference's helpers make, DSUNet.py:693,728)."""
+    from unet_amd.seeding import normal
+    from unet_amd.stft import DeviceSTFT
+    x = normal("stft/x", (5, L), seed=91)
+    win = torch.hann_window(512)
+    want = torch.stft(x, n_fft=512, window=win, return_complex=True)
+    tr = DeviceSTFT(512, win)
+    got = tr.stft(x.to(device))
+    assert tuple(got.shape) == tuple(want.shape)
+    assert_close(got, want, tol=2e-6, what="STFT")
+    back = tr.istft(got, L)
+    assert_close(back, torch.istft(want, n_fft=512, window=win, length=L), tol=1e-5, what="inverse STFT")
+    assert_close(back, x, tol=1e-5, what="STFT round trip")
+
+
+def test_dsunet_helper_wave_to_wave(device):
+    """DSUNet_helper end to end against the golden output of the reference and the oracle."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    arch = oracle.dsunet_architecture(45, 8)
+    ref = oracle.DSUNet_helper(arch).eval()
+    unet_amd.seeded_fill_(ref, seed=51)
+    dev = unet_amd.DSUNet_helper(unet_amd.dsunet_architecture(45, 8))
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    wav = normal("helper/x", (2, 4, 4000), seed=51) * 0.1
+    angle = uniform("helper/angle", (2,), 0.0, 360.0, seed=51)
+    mic = uniform("helper/mic", (2, 4, 3), -0.05, 0.05, seed=51)
+    with torch.no_grad():
+        want = ref(wav, angle, mic)
+        got = dev(wav.to(device), angle.to(device), mic.to(device))
+        sv = dev.steering_vector(angle.to(device), mic.to(device))
+        assert_close(sv, ref.steering_vector(angle, mic), tol=1e-5, what="steering vector")
+    golden = torch.from_numpy(load_golden("dsunet_helper_eval")["out"])
+    assert_close(want, golden, tol=1e-5, what="oracle vs golden")
+    assert_close(got, golden, what="helper HIP vs golden")
+    assert_close(got, want, what="helper HIP vs oracle")

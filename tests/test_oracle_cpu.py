@@ -153,3 +153,16 @@ def test_state_dict_keys_and_shape_rules():
         oracle.UNet([oracle.Encoder(2, 4, (3, 3), 1)], [])
     with pytest.raises(Exception, match="Unknown activation"):
         oracle.Encoder(2, 4, (3, 3), 1, activation="Swish")
+
+
+def test_dsunet_helper_matches_golden():
+    """Wave-in / wave-out wrapper (STFT, steering-vector features, DSUNet, mask, inverse STFT)."""
+    arch = oracle.dsunet_architecture(45, 8)
+    m = oracle.DSUNet_helper(arch).eval()
+    seeded_fill_(m, seed=51)
+    wav = normal("helper/x", (2, 4, 4000), seed=51) * 0.1
+    angle = uniform("helper/angle", (2,), 0.0, 360.0, seed=51)
+    mic = uniform("helper/mic", (2, 4, 3), -0.05, 0.05, seed=51)
+    with torch.no_grad():
+        y = m(wav, angle, mic)
+    assert_close(y, torch.from_numpy(load_golden("dsunet_helper_eval")["out"]), tol=CPU_TOL, what="DSUNet_helper")

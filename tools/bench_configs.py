@@ -6,6 +6,7 @@
            that is sharded over 8 GPUs, [32,14,257,509] fp32
   resunet  ResUNet forward, [32,4,257,501] fp32
   dsunet   DSUNet (UDSS.set_size(45, 8) table) forward, sf [32,8,257,512], SV [32,4,514], theta [32,2]
+  helper   DSUNet_helper, wave in -> wave out: [32,4,64000] samples, STFT and inverse STFT included
 
 One JSON line per workload: audio-seconds/s (4.0 s per utterance), ms per step and the algorithmic
 GFLOP per utterance it implies.  Run it under ``rocprofv3 --kernel-trace --stats`` for the per-kernel
@@ -92,6 +93,16 @@ def main():
             sec = timed(lambda: net(sf, SV, theta), args.steps, args.warmup)
             report("dsunet", sec, 129.76, "DSUNet(UDSS table, model_complexity 45, 8 inputs) forward, "
                                           "sf [B,8,257,512], SV [B,4,514], theta [B,2]", args.dtype)
+        if args.only in (None, "helper"):
+            net = unet_amd.DSUNet_helper(unet_amd.dsunet_architecture(45, 8))
+            unet_amd.seeded_fill_(net, seed=51)
+            net.eval().to(dev)
+            wav = (torch.randn((B, 4, 64000), generator=g) * 0.1).to(dev)
+            angle = (torch.rand((B,), generator=g) * 360).to(dev)
+            mic = ((torch.rand((B, 4, 3), generator=g) - 0.5) * 0.1).to(dev)
+            sec = timed(lambda: net(wav, angle, mic), args.steps, args.warmup)
+            report("helper", sec, 129.76, "DSUNet_helper wave -> wave: 4-channel 4 s 16 kHz audio, STFT + features + "
+                                          "DSUNet + mask + inverse STFT, [B,4,64000] -> [B,64000]")
 
 
 if __name__ == "__main__":

@@ -199,3 +199,74 @@ class DSUNet(nn.Module):
 
     def masking(self, X, M):
         return self.mask.output(X, M)
+
+
+class DSUNet_helper(nn.Module):
+    """Wave in, wave out: STFT -> spectral / steering-vector / angle features -> DSUNet -> complex mask
+    -> inverse STFT, with the reference's constructor and ``forward(x, angle, mic_pos)``
+    (DSUNet.py:634-790).  The two transforms run on the convolution kernels (unet_amd/stft.py), the
+    per-frequency Python loops of the reference's steering vector are closed-form tensor expressions,
+    and -- as in the reference -- the source distance is one Frobenius norm over the whole batch
+    (DSUNet.py:748), so all samples of a call share their delays."""
+
+    def __init__(self, architecture, n_fft=512, dropout=0.0, bottleneck="None", model_complexity=45, use_SV=True,
+                 mag_phase=False, corr=False, DSB=False, activation="LeakyReLU", type_norm="BatchNorm2d",
+                 type_masking="CRM", type_encoder="Encoder", type_residual="None"):
+        super().__init__()
+        from .stft import DeviceSTFT
+        self.n_fft = n_fft
+        self.n_hfft = n_fft // 2 + 1
+        self.n_channel = 4
+        model_channel = self.n_channel * 2 + (2 if DSB else 0)
+        self.mag_phase, self.use_SV, self.corr, self.DSB = mag_phase, use_SV, corr, DSB
+        self.net = DSUNet(architecture=architecture, input_channels=model_channel, dropout=dropout,
+                          bottleneck=bottleneck, model_complexity=model_complexity, activation=activation,
+                          type_norm=type_norm, type_masking=type_masking, type_encoder=type_encoder,
+                          type_residual=type_residual)
+        self.sr, self.ss, self.dist = 16000, 340.4, 100
+        self.window = torch.hann_window(self.n_fft)
+        self._stft = DeviceSTFT(n_fft, self.window)
+
+    def forward(self, x, angle, mic_pos):
+        require_device_tensor(x, "DSUNet_helper")
+        B, C, L = x.shape
+        X = self._stft.stft(x.reshape(B * C, L).contiguous())
+        T = X.shape[2]
+        X = torch.nn.functional.pad(X, (0, 16 - T % 16)).reshape(B, C, self.n_hfft, -1)
+        feat_src = X
+        if self.corr:
+            feat_src = torch.cat([X[:, :1], X[:, :1] * X[:, 1:]], dim=1)
+        SV = self.steering_vector(angle, mic_pos)
+        SV = torch.cat((SV.real, SV.imag), -1)
+        theta = self.anlge_pre(angle)
+        parts = [feat_src.real, feat_src.imag]
+        if self.DSB:
+            dsb = self.delay_n_sum(feat_src, angle, mic_pos)
+            parts.append(torch.stack((dsb.real, dsb.imag), dim=1))
+        spectral_feature = torch.cat(parts, dim=1).contiguous()
+        mask = self.net(spectral_feature, SV, theta)
+        Y = self.net.masking(feat_src[:, 0], mask)
+        return self._stft.istft(Y.contiguous(), L)
+
+    def anlge_pre(self, angle):
+        rad = (-angle) / 180 * torch.pi
+        return torch.stack((torch.sin(rad), torch.cos(rad)), 1)
+
+    def _phasors(self, angle, mic_pos, sign):
+        rad = (-angle) / 180 * torch.pi
+        loc_src = torch.stack((self.dist * torch.cos(rad), self.dist * torch.sin(rad), torch.zeros_like(rad)), dim=1)
+        loc_src[:, 2] = self.dist * torch.cos(torch.tensor(torch.pi / 2))
+        # one norm over the whole [B,3] difference per microphone, as the reference computes it
+        dist = torch.stack([torch.linalg.norm(mic_pos[:, i] - loc_src) for i in range(self.n_channel)])
+        tdoa = (dist - dist[0])[None, :].expand(angle.shape[0], -1)                          # [B, C]
+        const = sign * 2 * torch.pi * self.sr / (self.n_fft * self.ss)
+        j = torch.arange(self.n_hfft, device=angle.device, dtype=torch.float32)
+        phase = tdoa[:, :, None] * j[None, None, :] * const                                   # [B, C, F]
+        out = torch.polar(torch.ones_like(phase), phase)
+        return out / torch.linalg.norm(out, dim=1, keepdim=True)
+
+    def steering_vector(self, angle, mic_pos):
+        return self._phasors(angle, mic_pos, -1)
+
+    def delay_n_sum(self, X, angle, mic_pos):
+        return torch.einsum("bcft,bcf->bft", X, self._phasors(angle, mic_pos, +1))
