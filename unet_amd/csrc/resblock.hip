@@ -301,13 +301,13 @@ static hipError_t launch_resblock_t(int grid, hipStream_t s, const ResblockArgs&
     return hipGetLastError();
 }
 
-// Tile width per storage type (measured on the 257 x 501 level of ResUNet at batch 32): 64 columns for
-// fp32, 32 for bfloat16, whose 2-byte accesses gain more from the extra resident workgroups.
-static int tile_cols(bool bf16) { return bf16 ? 32 : 64; }
+// Tile width: 64 columns.  The 32-column instantiation (half the accumulators, four resident workgroups
+// instead of two) measured slower inside ResUNet for both storage types; it stays selectable here.
+static int tile_cols(bool) { return 64; }
 
 template <int D, bool DWISE>
 static hipError_t launch_resblock(int grid, hipStream_t s, const ResblockArgs& a, bool bf16) {
-    return bf16 ? launch_resblock_t<D, DWISE, true, 32>(grid, s, a) : launch_resblock_t<D, DWISE, false, 64>(grid, s, a);
+    return bf16 ? launch_resblock_t<D, DWISE, true, 64>(grid, s, a) : launch_resblock_t<D, DWISE, false, 64>(grid, s, a);
 }
 
 static int fill_tiles(ResblockArgs& a, bool bf16) {
