@@ -14,11 +14,19 @@
 //
 // A workgroup (4 waves) owns: one row phase, TI phase-rows x 32 phase-columns x
 // all column phases, and NB (32|64) output channels.  Channels are consumed in
-// chunks: while the MFMAs of chunk c run out of LDS, the global loads of chunk
-// c+1 (input patch [ci][rows][cols], zero outside the image, plus that chunk's
-// weights, already in read order) are in flight into registers; they are
-// written to LDS between two barriers.  LDS <= 64 KB so two workgroups share a
-// CU and the matrix pipe of a SIMD always has a second wave to issue from.
+// chunks (a concatenated input is chunked per source tensor, so a chunk streams
+// from one tensor).  Two kernels share the MFMA loop and the epilogue:
+//   * conv_dma_kernel (conv_dma_kernel.hpp), the default: the LDS image of a chunk
+//     (input patch [ci][rows][cols], zero outside the image, plus that chunk's
+//     weights, already in read order) is double-buffered and filled by LDS-DMA
+//     (buffer_load ... lds), one DMA instruction issued per tap from inside the
+//     MFMA loop, one barrier per chunk.  The image size is chosen per layer so
+//     that three (25 KB images) or two (38 KB) workgroups share a compute unit.
+//   * conv_mfma_kernel (conv_kernel.hpp), register-staged: the next chunk's global
+//     loads are in flight in registers while the current chunk computes and are
+//     written to LDS between two barriers.  It serves the summed two-source input
+//     (the loads of both tensors are added on the way into LDS) and bfloat16
+//     storage (the loads are widened in registers).
 #include "conv_kernel.hpp"
 
 namespace unetmi {

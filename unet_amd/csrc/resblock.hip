@@ -10,8 +10,8 @@
 //   * the chunk's input patch [chunk][6][64+2d] is fetched with unconditional buffer loads (lanes
 //     outside the image carry an out-of-range offset and read 0 = the zero padding) while the
 //     previous chunk computes, then parked in LDS;
-//   * the depthwise 3x3 runs on the vector ALUs (thread = one time step x 4 channels x 4 rows, so
-//     each patch value is read from LDS once per thread) and leaves its result in LDS as the B
+//   * the depthwise 3x3 runs on the vector ALUs (thread = one time step x 2 channels x 4 rows: the six
+//     patch rows it reads serve all four output rows) and leaves its result in LDS as the B
 //     operand [channel][pixel] of the pointwise product;
 //   * the pointwise 64x64 product runs on v_mfma_f32_32x32x2_f32 with the whole weight matrix kept
 //     in LDS in operand order for the life of the workgroup; wave w owns image row w of the tile.
@@ -52,10 +52,6 @@ struct ResblockArgs {
     int ablate;             // developer probe (environment UNETMI_RB_ABLATE): bit mask of stages to skip
 };
 
-__device__ __forceinline__ float rb_load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-}
-
 // DWISE = false drops the depthwise stage: a plain 64 -> 64 pointwise convolution (D = 0, no halo),
 // whose input chunk is parked straight into the B-operand layout.
 // TC = tile columns (64 or 32).  The narrower tile halves the accumulators (32 registers), which lets four
@@ -85,7 +81,7 @@ __global__ __launch_bounds__(256, TC == 32 ? 4 : 2) void resblock_layer_kernel(c
     float* s_dw = s_par + 3 * kRbC;                       // [64][10] depthwise taps + bias
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: lets per-channel constants be scalar loads
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction; tell the compiler
     const int HW = a.H * a.W;
 
     // pointwise weights in MFMA operand order: A operand of k-step ks, output tile t, lane l is
@@ -107,7 +103,7 @@ __global__ __launch_bounds__(256, TC == 32 ? 4 : 2) void resblock_layer_kernel(c
     }
     const float alpha = a.alpha ? a.alpha[0] : 1.f;
 
-    // depthwise work of this thread: column dcol of the tile, a quarter of the chunk's channels
+    // depthwise work of this thread: column dcol of the tile, CK/DG of the chunk's channels
     const int dcol = tid % TC, dch0 = (tid / TC) * (kRbCK / DG);
 
     int voff[NSLOT];
