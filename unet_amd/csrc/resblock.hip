@@ -19,7 +19,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
 #include <string>
 #include <type_traits>
 
@@ -49,7 +48,6 @@ struct ResblockArgs {
     void* out;
     int N, H, W, residual, act_first;
     int tiles_h, tiles_w, ntiles;
-    int ablate;             // developer probe (environment UNETMI_RB_ABLATE): bit mask of stages to skip
 };
 
 // DWISE = false drops the depthwise stage: a plain 64 -> 64 pointwise convolution (D = 0, no halo),
@@ -128,7 +126,7 @@ __global__ __launch_bounds__(256, TC == 32 ? 4 : 2) void resblock_layer_kernel(c
             const_cast<char*>(static_cast<const char*>(a.x) + (size_t)n * kRbC * HW * EB), 0, kRbC * HW * EB, 0x00020000);
         const int soff = chunk * kRbCK * HW * EB;
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) stage[s] = (a.ablate & 16) ? 0.f : buf_ld_act<BF16>(rs0, voff[s], soff);
+        for (int s = 0; s < NSLOT; ++s) stage[s] = buf_ld_act<BF16>(rs0, voff[s], soff);
         if (a.x2) {
             const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(static_cast<const char*>(a.x2) + (size_t)n * kRbC * HW * EB), 0, kRbC * HW * EB, 0x00020000);
@@ -177,7 +175,7 @@ __global__ __launch_bounds__(256, TC == 32 ? 4 : 2) void resblock_layer_kernel(c
         auto fetch_residual = [&]() {
             const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(static_cast<const char*>(a.x) + (size_t)n * kRbC * HW * EB), 0,
-                (a.residual && !(a.ablate & 2)) ? kRbC * HW * EB : 0, 0x00020000);
+                a.residual ? kRbC * HW * EB : 0, 0x00020000);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -194,7 +192,7 @@ __global__ __launch_bounds__(256, TC == 32 ? 4 : 2) void resblock_layer_kernel(c
             constexpr bool LAST = decltype(last_tag)::value;
             if (!LAST) fetch(n, chunk + 1);
             else fetch_residual();
-            if (DWISE && !(a.ablate & 4)) {
+            if (DWISE) {
                 // ---- depthwise 3x3, dilation (1, D) ---- (one channel at a time: keeps the live set small)
 #pragma nounroll
                 for (int cc = 0; cc < kRbCK / DG; ++cc) {
@@ -221,7 +219,6 @@ __global__ __launch_bounds__(256, TC == 32 ? 4 : 2) void resblock_layer_kernel(c
                 __syncthreads();
             }
             // ---- pointwise product over this chunk's input channels ----
-            if (!(a.ablate & 8))
 #pragma unroll
             for (int ks = 0; ks < kRbCK / 2; ++ks) {
                 const int gks = chunk * (kRbCK / 2) + ks;
@@ -270,7 +267,7 @@ __global__ __launch_bounds__(256, TC == 32 ? 4 : 2) void resblock_layer_kernel(c
                         v = v >= 0.f ? v : alpha * v;
                     }
                     v += res[t][h][r];
-                    if (!(a.ablate & 1) || v == 123.456f) buf_st_act<BF16>(v, rs_out, obase[h], cou * HW * EB);
+                    buf_st_act<BF16>(v, rs_out, obase[h], cou * HW * EB);
                 }
             }
         if (next < a.ntiles) {
@@ -308,8 +305,6 @@ static hipError_t launch_resblock(int grid, hipStream_t s, const ResblockArgs& a
 
 static int fill_tiles(ResblockArgs& a, bool bf16) {
     const int tc = tile_cols(bf16);
-    const char* ab = std::getenv("UNETMI_RB_ABLATE");
-    a.ablate = ab ? std::atoi(ab) : 0;
     a.tiles_h = (a.H + kRbTR - 1) / kRbTR; a.tiles_w = (a.W + tc - 1) / tc;
     const long long nt = (long long)a.N * a.tiles_h * a.tiles_w;
     if (nt > 0x7fffffffll) return -1;
