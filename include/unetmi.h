@@ -200,6 +200,16 @@ int unetmi_layernorm_f_fwd(int N, int C, int F, int T, int C_out, int c_off, flo
 int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const void* y, const void* x, void* out,
                          int dtype, void* stream);
 
+/* Gate stage of DSUNet's gated convolutions (GConv / TrGConv, DSUNet.py:134-172, :241-275), which compute
+ * sigmoid(conv_m(x)) * conv_c(x) [-> norm -> activation].  The two convolutions share geometry and input, so
+ * they run as ONE unetmi_conv2d_fwd launch with the weights stacked to 2K output channels (features first,
+ * mask logits second); this entry point finishes the layer in one bandwidth-bound pass:
+ *   out[n,k,i] = gate[n,k] * act(scale[k] * (sigmoid(z[n,K+k,i]) * z[n,k,i]) + shift[k])
+ * z [N,2K,HW], out [N,K,HW] (UNETMI_DTYPE_* storage); scale/shift (folded eval BatchNorm) [K] or null,
+ * act_param [1] or null, gate [N,K] or null (DSUNet's attractor gate, DSUNet.py:599-602). */
+int unetmi_glu_fwd(int N, int K, int HW, const void* z, const float* scale, const float* shift, int act,
+                   const float* act_param, const float* gate, void* out, int dtype, void* stream);
+
 /* Complex ratio filter / complex mask application over the STFT:
  *   Y[b,n,c,f,t] = sum_{p<PF, q<PT} Hf[b,n,c,p,q,f,t] * X[b,c,f+p-(PF-1)/2, t+q-(PT-1)/2]   (zero outside)
  * Hf: complex64 [B,N,C,PF,PT,F,T] (the tensor cRFUNet.UNet20.forward returns, cRFUNet.py:320-324);

@@ -213,3 +213,129 @@ class CRM(nn.Module):
 
     def output(self, X, M):
         return X * M
+
+
+def _gconv_norm(type_norm, channels):
+    # DSUNet.py:144-149: any other name is the identity
+    if type_norm == "BatchNorm2d":
+        return nn.BatchNorm2d(channels)
+    if type_norm == "InstanceNorm2d":
+        return nn.InstanceNorm2d(channels, track_running_stats=True)
+    return nn.Identity()
+
+
+def _gconv_activation(name):
+    # DSUNet.py:151-162 (no else branch: an unknown name leaves the attribute unset in the reference)
+    return {"ReLU": nn.ReLU, "SiLU": nn.SiLU, "ELU": nn.ELU, "Softplus": nn.Softplus, "PReLU": nn.PReLU,
+            "LeakyReLU": nn.LeakyReLU}[name]()
+
+
+class GConv(nn.Module):
+    """Gated convolution: sigmoid(conv_m(x)) * conv_c(x) -> norm -> activation.  Restates DSUNet.py:134-172."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, groups=1,
+                 type_norm="BatchNorm2d", activation="ReLU", dropout=0.0):
+        super().__init__()
+        self.c = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                           groups=groups)
+        self.m = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                         padding=padding, groups=groups), nn.Sigmoid())
+        self.norm = _gconv_norm(type_norm, out_channels)
+        self.activation = _gconv_activation(activation)
+
+    def forward(self, x):
+        return self.activation(self.norm(self.m(x) * self.c(x)))
+
+
+class TrGConv(nn.Module):
+    """Gated transposed convolution.  Restates DSUNet.py:241-275: the norm and the activation are
+    constructed but NOT applied in forward."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, groups=1,
+                 type_norm="BatchNorm2d", activation="ReLU", dropout=0.0):
+        super().__init__()
+        self.c = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                    padding=padding, output_padding=output_padding, groups=groups)
+        self.m = nn.Sequential(nn.ConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                                  padding=padding, output_padding=output_padding, groups=groups),
+                               nn.Sigmoid())
+        self.norm_point = _gconv_norm(type_norm, out_channels)
+        self.activation = _gconv_activation(activation)
+
+    def forward(self, x):
+        return self.m(x) * self.c(x)
+
+
+class TGRUBlock(nn.Module):
+    """GRU along time for every (batch, frequency) row, then 1x1 conv -> BN -> ReLU.  Restates DSUNet.py:281-312."""
+
+    def __init__(self, in_channels, hidden_size, out_channels, skipGRU=False, **kwargs):
+        super().__init__()
+        if skipGRU:
+            raise Exception("Not Implemented")
+        self.GRU = nn.GRU(in_channels, hidden_size, batch_first=True)
+        self.conv = nn.Conv2d(hidden_size, out_channels, kernel_size=1)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.hidden_size = hidden_size
+        self.relu = nn.ReLU()
+
+    def forward(self, x, rnn_state=None):
+        B, C, F, T = x.shape
+        x_ = x.permute(0, 2, 3, 1).reshape(B * F, T, C)
+        y_, rnn_state = self.GRU(x_, rnn_state)
+        y2 = y_.reshape(B, F, T, self.hidden_size).permute(0, 3, 1, 2)
+        return self.relu(self.bn(self.conv(y2)))
+
+
+class SEBlock(nn.Module):
+    """Squeeze-and-excitation scale.  Restates DSUNet.py:317-346."""
+
+    def __init__(self, in_channel, ratio=16):
+        super().__init__()
+        size_se = int(in_channel / ratio)
+        self.pool = torch.nn.AdaptiveAvgPool2d((1, 1))
+        self.squeeze = nn.Linear(in_channel, size_se)
+        self.relu = nn.ReLU()
+        self.excitation = nn.Linear(size_se, in_channel)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        x_ = self.pool(x).permute(0, 2, 3, 1)
+        x_ = self.sigmoid(self.excitation(self.relu(self.squeeze(x_)))).permute(0, 3, 1, 2)
+        return x * x_
+
+
+class CRM_sig(nn.Module):
+    """DSUNet.py:364-375."""
+
+    def forward(self, x):
+        m = torch.sigmoid(x)
+        return m[:, 0, ...] + 1j * m[:, 1, ...]
+
+    def output(self, X, M):
+        return X * M
+
+
+class CRM_soft(nn.Module):
+    """DSUNet.py:377-390."""
+
+    def __init__(self):
+        super().__init__()
+        self.masking = nn.Softplus()
+
+    def forward(self, x):
+        m = self.masking(x)
+        return m[:, 0, ...] + 1j * m[:, 1, ...]
+
+    def output(self, X, M):
+        return X * M
+
+
+class CM(nn.Module):
+    """Complex mapping: the network output IS the spectrum.  DSUNet.py:393-402."""
+
+    def forward(self, x):
+        return x[:, 0, ...] + 1j * x[:, 1, ...]
+
+    def output(self, X, M):
+        return M

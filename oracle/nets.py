@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .blocks import (Encoder, Decoder, ResBlock, DSEncoder, DSDecoder, Attractor,
-                     AttractEncoder, CRM)
+                     AttractEncoder, CRM, CRM_sig, CRM_soft, CM, GConv, TrGConv, TGRUBlock, SEBlock)
 from .tables import unet20_layers
 
 
@@ -200,16 +200,23 @@ class DSUNet(nn.Module):
     """Directional-separating U-Net built from an external architecture dict
     (keys ``encoder.enc{1..L}`` / ``decoder.dec{L..1}``); each encoder output is
     gated per (batch, channel) by a code of steering vector + angle; CRM head.
-    Restates DSUNet.py:467-631 for type_encoder="Encoder", bottleneck="None",
-    type_residual="None", type_masking="CRM" (the defaults)."""
+    Restates DSUNet.py:467-631 for type_encoder "Encoder" / "GConv", bottleneck "None" / "TGRU",
+    type_residual "None" / "SE" (which the reference builds on the wrong channel count, so its forward
+    raises), type_masking "CRM" / "CRM_sig" / "CRM_soft" / "CM"."""
 
     def __init__(self, architecture, input_channels=8, n_fft=512, model_complexity=45,
                  bottleneck="None", padding_mode="zeros", type_masking="CRM",
                  activation="LeakyReLU", dropout=0.0, type_norm="BatcNorm2d",
                  type_encoder="Encoder", type_residual="None"):
         super().__init__()
-        if type_encoder != "Encoder" or type_masking != "CRM" or bottleneck != "None" \
-                or type_residual != "None":
+        if type_encoder == "Encoder":
+            enc_cls, dec_cls = DSEncoder, DSDecoder
+        elif type_encoder == "GConv":
+            enc_cls, dec_cls = GConv, TrGConv
+        else:
+            raise Exception("Not Implemented Encoder")
+        heads = {"CRM": CRM, "CRM_sig": CRM_sig, "CRM_soft": CRM_soft, "CM": CM}
+        if type_masking not in heads:
             raise Exception("Not Implemented")
         self.bottleneck = bottleneck
         self.n_channel = input_channels
@@ -218,14 +225,14 @@ class DSUNet(nn.Module):
         enc_kw = [architecture["encoder"]["enc{}".format(i + 1)] for i in range(L)]
         dec_kw = [architecture["decoder"]["dec{}".format(L - i)] for i in range(L)]
 
-        encs = [DSEncoder(**kw) for kw in enc_kw]
+        encs = [enc_cls(**kw) for kw in enc_kw]
         for i, m in enumerate(encs):
             self.add_module("encoder{}".format(i), m)
-        decs = [DSDecoder(**kw) for kw in dec_kw]
+        decs = [dec_cls(**kw) for kw in dec_kw]
         for i, m in enumerate(decs):
             self.add_module("decoder{}".format(i), m)
-        self.BTN = nn.Identity()
-        res = [nn.Identity() for _ in range(L - 1)]
+        self.BTN = TGRUBlock(128, 128, 128) if bottleneck == "TGRU" else nn.Identity()
+        res = [SEBlock(enc_kw[i]["out_channels"]) if type_residual == "SE" else nn.Identity() for i in range(L - 1)]
         for i, m in enumerate(res):
             self.add_module("res{}".format(i), m)
         self.Attractor = Attractor(n_ch=4, n_fft=n_fft)
@@ -234,7 +241,7 @@ class DSUNet(nn.Module):
             self.add_module("attractEncoder_{}".format(i), m)
         self.add_module("linear", nn.Conv2d(architecture["decoder"]["dec1"]["out_channels"], 2, 1))
         self.padding_mode = padding_mode
-        self.mask = CRM()
+        self.mask = heads[type_masking]()
         self.dr = nn.Dropout(self.dropout)
         # the reference re-registers the same modules in ModuleLists
         # (DSUNet.py:577-580), which doubles their state_dict keys

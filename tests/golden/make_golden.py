@@ -250,6 +250,34 @@ def main():
         save("dsunet_eval", out=torch.view_as_real(y_ref).numpy(),
              masked=torch.view_as_real(ref.masking(X, y_ref)).numpy())
 
+    # ---------------------------------------------------------------- DSUNet variants
+    variants = {"gconv": dict(type_encoder="GConv"), "tgru": dict(bottleneck="TGRU"),
+                "crm_sig": dict(type_masking="CRM_sig"), "crm_soft": dict(type_masking="CRM_soft"),
+                "cm": dict(type_masking="CM")}
+    var_out = {}
+    for vname, kw in variants.items():
+        print("DSUNet variant {} {}, B=2 F=257 T=16".format(vname, kw))
+        ref = R_ds.DSUNet(arch, **kw)
+        seeded_fill_(ref, seed=43)
+        mine = oracle.DSUNet(arch, **kw)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        assert sorted(ref.state_dict().keys()) == sorted(mine.state_dict().keys())
+        ref.eval(), mine.eval()
+        with torch.no_grad():
+            y_ref, y_mine = ref(sf, SV, theta), mine(sf, SV, theta)
+        require_equal(y_ref, y_mine, "DSUNet " + vname)
+        var_out[vname] = torch.view_as_real(y_ref).numpy()
+    try:
+        with torch.no_grad():
+            R_ds.DSUNet(arch, type_residual="SE").eval()(sf, SV, theta)
+        se_fact = "ok"
+    except RuntimeError:
+        se_fact = "RuntimeError"
+    print("  DSUNet(type_residual='SE') forward:", se_fact)
+    assert se_fact == "RuntimeError"
+    if out is not None:
+        save("dsunet_variants_eval", **var_out)
+
     # ---------------------------------------------------------------- DSUNet_helper (wave in, wave out)
     print("DSUNet_helper (STFT -> features -> DSUNet -> CRM -> iSTFT), B=2 C=4 L=4000")
     ref = R_ds.DSUNet_helper(arch)

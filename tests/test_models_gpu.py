@@ -305,3 +305,35 @@ def test_dsunet_helper_wave_to_wave(device):
     assert_close(want, golden, tol=1e-5, what="oracle vs golden")
     assert_close(got, golden, what="helper HIP vs golden")
     assert_close(got, want, what="helper HIP vs oracle")
+
+
+@pytest.mark.parametrize("variant,kw", [("gconv", dict(type_encoder="GConv")), ("tgru", dict(bottleneck="TGRU")),
+                                        ("crm_sig", dict(type_masking="CRM_sig")), ("crm_soft", dict(type_masking="CRM_soft")),
+                                        ("cm", dict(type_masking="CM"))])
+def test_dsunet_variants_match_golden_and_oracle(device, variant, kw):
+    """DSUNet with gated convolutions, the time-GRU bottleneck and the other mask heads."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.DSUNet(oracle.dsunet_architecture(45, 8), **kw).eval()
+    unet_amd.seeded_fill_(ref, seed=43)
+    dev = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8), **kw)
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    sf = normal("dsunet/sf", (2, 8, 257, 16), seed=41)
+    SV = normal("dsunet/SV", (2, 4, 514), seed=41)
+    ang = uniform("dsunet/theta", (2,), 0.0, 2 * np.pi, seed=41)
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    with torch.no_grad():
+        want = ref(sf, SV, theta)
+        got = dev(sf.to(device), SV.to(device), theta.to(device))
+    golden = torch.view_as_complex(torch.from_numpy(load_golden("dsunet_variants_eval")[variant]).contiguous())
+    assert_close(want, golden, tol=1e-5, what="oracle vs golden")
+    assert_close(got, golden, what="DSUNet {} HIP vs golden".format(variant))
+    assert_close(got, want, what="DSUNet {} HIP vs oracle".format(variant))
+
+
+def test_dsunet_se_residual_is_refused(device):
+    import unet_amd
+    with pytest.raises(Exception):
+        unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8), type_residual="SE")

@@ -166,3 +166,18 @@ def test_dsunet_helper_matches_golden():
     with torch.no_grad():
         y = m(wav, angle, mic)
     assert_close(y, torch.from_numpy(load_golden("dsunet_helper_eval")["out"]), tol=CPU_TOL, what="DSUNet_helper")
+
+
+@pytest.mark.parametrize("variant,kw", [("gconv", dict(type_encoder="GConv")), ("tgru", dict(bottleneck="TGRU")),
+                                        ("crm_soft", dict(type_masking="CRM_soft")), ("cm", dict(type_masking="CM"))])
+def test_dsunet_variants_match_golden(variant, kw):
+    m = oracle.DSUNet(oracle.dsunet_architecture(45, 8), **kw).eval()
+    seeded_fill_(m, seed=43)
+    sf = normal("dsunet/sf", (2, 8, 257, 16), seed=41)
+    SV = normal("dsunet/SV", (2, 4, 514), seed=41)
+    ang = uniform("dsunet/theta", (2,), 0.0, 2 * np.pi, seed=41)
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    with torch.no_grad():
+        y = m(sf, SV, theta)
+    golden = torch.view_as_complex(torch.from_numpy(load_golden("dsunet_variants_eval")[variant]).contiguous())
+    assert_close(y, golden, tol=CPU_TOL, what="DSUNet " + variant)

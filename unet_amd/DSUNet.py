@@ -6,15 +6,18 @@ per-(batch, channel) gate ``max(sigmoid(Linear(code)), 1/C)`` that the reference
 multiplies in afterwards (DSUNet.py:599-602).  Decoders read ``[p, skip]`` as two
 kernel inputs.  The 1x1 ``linear`` head with the complex-ratio-mask tanh is one
 more fused launch.  The attractor MLP (0.8 MFLOP per utterance) runs as ordinary
-torch device ops.  Supported variants: the constructor defaults
-(type_encoder="Encoder", bottleneck="None", type_residual="None",
-type_masking in CRM / CRM_sig / CRM_soft / CM).
+torch device ops.  Supported variants: type_encoder "Encoder" / "GConv" (gated
+convolutions: both convolutions of a layer in one double-width launch, then one gate
+pass), bottleneck "None" / "TGRU", type_masking CRM / CRM_sig / CRM_soft / CM.
+type_residual "SE" is refused: the reference builds its SE blocks on the wrong channel
+count and its forward raises (DSUNet.py:541-545, :588).
 """
 
 import torch
 import torch.nn as nn
 
-from .fused import FusedConv, require_device_tensor
+from .fused import FusedConv, activation_code, require_device_tensor
+from .ops import glu
 
 
 def _activation(name):
@@ -74,6 +77,142 @@ class Decoder(_Block):
 
     def forward(self, x, skip=None):
         return self._run(self.transconv, x, skip)
+
+
+def _gconv_norm(type_norm, channels):
+    # DSUNet.py:144-149
+    if type_norm == "BatchNorm2d":
+        return nn.BatchNorm2d(channels)
+    if type_norm == "InstanceNorm2d":
+        return nn.InstanceNorm2d(channels, track_running_stats=True)
+    return nn.Identity()
+
+
+def _gconv_activation(name):
+    # DSUNet.py:151-162
+    return {"ReLU": nn.ReLU, "SiLU": nn.SiLU, "ELU": nn.ELU, "Softplus": nn.Softplus, "PReLU": nn.PReLU,
+            "LeakyReLU": nn.LeakyReLU}[name]()
+
+
+class _Gated(nn.Module):
+    """sigmoid(conv_m(x)) * conv_c(x): the two convolutions share input and geometry, so they run as
+    one launch of a convolution with the weights stacked to 2K output channels (rebuilt when a
+    parameter changes), followed by one gate pass (unetmi_glu_fwd) that also carries the layer's
+    BatchNorm affine, activation and DSUNet's attractor gate."""
+
+    def _stacked(self, c, m):
+        key = tuple((t._version, t.data_ptr()) for t in (c.weight, c.bias, m.weight, m.bias))
+        if self._twin is None or self._twin_key != key:
+            transposed = isinstance(c, nn.ConvTranspose2d)
+            kw = dict(kernel_size=c.kernel_size, stride=c.stride, padding=c.padding)
+            if transposed:
+                twin = nn.ConvTranspose2d(c.in_channels, 2 * c.out_channels, output_padding=c.output_padding, **kw)
+            else:
+                twin = nn.Conv2d(c.in_channels, 2 * c.out_channels, **kw)
+            with torch.no_grad():
+                twin = twin.to(c.weight.device)
+                twin.weight.copy_(torch.cat([c.weight, m.weight], dim=1 if transposed else 0))
+                twin.bias.copy_(torch.cat([c.bias, m.bias]))
+            object.__setattr__(self, "_twin", FusedConv(twin))
+            object.__setattr__(self, "_twin_key", key)
+        return self._twin
+
+    def _gated(self, x, skip, norm, act, gate):
+        require_device_tensor(x, type(self).__name__)
+        if self.training:
+            raise NotImplementedError("{}: train-mode forward is not available in this build; call .eval()"
+                                      .format(type(self).__name__))
+        c, m = self.c, self.m[0]
+        if c.groups != 1:
+            raise NotImplementedError("grouped gated convolutions are not built")
+        z = self._stacked(c, m)(x, skip)
+        scale = shift = None
+        post_norm = None
+        if isinstance(norm, nn.BatchNorm2d):
+            inv = torch.rsqrt(norm.running_var.float() + norm.eps)
+            scale = (norm.weight.float() * inv).contiguous()
+            shift = (norm.bias.float() - norm.running_mean.float() * scale).contiguous()
+        elif norm is not None and not isinstance(norm, nn.Identity):
+            post_norm = norm
+        found = activation_code(act) if post_norm is None else None
+        if found is None or (isinstance(found[1], torch.Tensor) and found[1].numel() != 1):
+            y = glu(z, scale, shift, 0, None, None)                  # gate product (+ BatchNorm) on the device kernel
+            if post_norm is not None:
+                y = post_norm(y)
+            y = act(y) if act is not None else y
+            return y if gate is None else y * gate[:, :, None, None]
+        code, par = found
+        if isinstance(par, torch.Tensor):
+            par = par.detach().float().reshape(1)
+        elif par is not None:
+            par = torch.full((1,), par, dtype=torch.float32, device=x.device)
+        return glu(z, scale, shift, code, par, gate)
+
+
+class GConv(_Gated):
+    """Gated convolution block (DSUNet.py:134-172)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, groups=1,
+                 type_norm="BatchNorm2d", activation="ReLU", dropout=0.0):
+        super().__init__()
+        self.c = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                           groups=groups)
+        self.m = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                         padding=padding, groups=groups), nn.Sigmoid())
+        self.norm = _gconv_norm(type_norm, out_channels)
+        self.activation = _gconv_activation(activation)
+        self._twin = self._twin_key = None
+
+    def forward(self, x, gate=None):
+        return self._gated(x, None, self.norm, self.activation, gate)
+
+
+class TrGConv(_Gated):
+    """Gated transposed convolution (DSUNet.py:241-275); as in the reference, its norm and
+    activation are constructed but not applied."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, groups=1,
+                 type_norm="BatchNorm2d", activation="ReLU", dropout=0.0):
+        super().__init__()
+        self.c = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                    padding=padding, output_padding=output_padding, groups=groups)
+        self.m = nn.Sequential(nn.ConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                                  padding=padding, output_padding=output_padding, groups=groups),
+                               nn.Sigmoid())
+        self.norm_point = _gconv_norm(type_norm, out_channels)
+        self.activation = _gconv_activation(activation)
+        self._twin = self._twin_key = None
+
+    def forward(self, x, skip=None):
+        return self._gated(x, skip, None, None, None)
+
+
+class TGRUBlock(nn.Module):
+    """GRU along time for every (batch, frequency) row (torch's device GRU), then 1x1 conv + BatchNorm +
+    ReLU as one fused launch (DSUNet.py:281-312)."""
+
+    def __init__(self, in_channels, hidden_size, out_channels, skipGRU=False, **kwargs):
+        super().__init__()
+        if skipGRU:
+            raise Exception("Not Implemented")
+        self.GRU = nn.GRU(in_channels, hidden_size, batch_first=True)
+        self.conv = nn.Conv2d(hidden_size, out_channels, kernel_size=1)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.hidden_size = hidden_size
+        self.relu = nn.ReLU()
+        self._fused = None
+
+    def forward(self, x, rnn_state=None):
+        require_device_tensor(x, "TGRUBlock")
+        B, C, F, T = x.shape
+        x_ = x.permute(0, 2, 3, 1).reshape(B * F, T, C)
+        y_, rnn_state = self.GRU(x_.float(), rnn_state)
+        y2 = y_.reshape(B, F, T, self.hidden_size).permute(0, 3, 1, 2).contiguous().to(x.dtype)
+        if self._fused is None:
+            object.__setattr__(self, "_fused", FusedConv(self.conv, self.bn, self.relu))
+        if self.training or not self._fused.fusable():
+            raise NotImplementedError("TGRUBlock: eval-mode BatchNorm only")
+        return self._fused(y2)
 
 
 class Attractor(nn.Module):
@@ -146,9 +285,13 @@ class DSUNet(nn.Module):
                  padding_mode="zeros", type_masking="CRM", activation="LeakyReLU", dropout=0.0,
                  type_norm="BatcNorm2d", type_encoder="Encoder", type_residual="None"):
         super().__init__()
-        if type_encoder != "Encoder":
-            raise Exception("Not Implemented Encoder")       # EncoderDWN / GConv: not built here
-        if bottleneck != "None" or type_residual != "None":
+        if type_encoder == "Encoder":
+            enc_cls, dec_cls = Encoder, Decoder
+        elif type_encoder == "GConv":
+            enc_cls, dec_cls = GConv, TrGConv
+        else:
+            raise Exception("Not Implemented Encoder")       # EncoderDWN: fails in the reference for in != out channels
+        if bottleneck not in ("None", "TGRU") or type_residual != "None":
             raise Exception("Not Implemented")
         self.bottleneck = bottleneck
         self.n_channel = input_channels
@@ -156,13 +299,13 @@ class DSUNet(nn.Module):
         self.dropout = dropout
         L = self.n_layer = len(architecture["encoder"])
         enc_kw = [architecture["encoder"]["enc{}".format(i + 1)] for i in range(L)]
-        encs = [Encoder(**kw) for kw in enc_kw]
+        encs = [enc_cls(**kw) for kw in enc_kw]
         for i, m in enumerate(encs):
             self.add_module("encoder{}".format(i), m)
-        decs = [Decoder(**architecture["decoder"]["dec{}".format(L - i)]) for i in range(L)]
+        decs = [dec_cls(**architecture["decoder"]["dec{}".format(L - i)]) for i in range(L)]
         for i, m in enumerate(decs):
             self.add_module("decoder{}".format(i), m)
-        self.BTN = nn.Identity()
+        self.BTN = TGRUBlock(128, 128, 128) if bottleneck == "TGRU" else nn.Identity()
         res = [nn.Identity() for _ in range(L - 1)]
         for i, m in enumerate(res):
             self.add_module("res{}".format(i), m)

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "unetmi_resblock_layer_fwd",
     "unetmi_pwconv64_fwd",
     "unetmi_lstm_recurrence",
+    "unetmi_glu_fwd",
 )
 
 
@@ -95,6 +96,8 @@ def _load():
     lib.unetmi_pwconv64_fwd.restype = ctypes.c_int
     lib.unetmi_lstm_recurrence.argtypes = [ci] * 3 + [fp] * 3 + [vp, vp]
     lib.unetmi_lstm_recurrence.restype = ctypes.c_int
+    lib.unetmi_glu_fwd.argtypes = [ci] * 3 + [fp] * 3 + [ci] + [fp] * 3 + [ci, vp]
+    lib.unetmi_glu_fwd.restype = ctypes.c_int
     lib.unetmi_adam_step.argtypes = [sz] + [fp] * 4 + [cf] * 6 + [ci, vp]
     for f in (lib.unetmi_bn_train_stats, lib.unetmi_bn_act_fwd, lib.unetmi_bn_act_bwd, lib.unetmi_conv2d_wgrad,
               lib.unetmi_adam_step):

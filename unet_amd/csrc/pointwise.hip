@@ -80,6 +80,42 @@ __global__ __launch_bounds__(256) void tanh_mask_kernel(const void* __restrict__
     st_act<BF16>(out, i, (tanhf(ld_act<BF16>(y, i)) + eps) * ld_act<BF16>(x, (n * Cx + k) * HW + sp));
 }
 
+// Gated-convolution epilogue: z[N,2K,HW] holds the feature conv in channels [0,K) and the mask conv's
+// logits in [K,2K) (one double-width convolution launch); out[n,k] = gate[n,k] * act(scale[k] * (sigmoid(m) * c) + shift[k]).
+__device__ __forceinline__ float glu_act(int act, float u, float p) {
+    switch (act) {
+        case UNETMI_ACT_LEAKY: return u >= 0.f ? u : p * u;
+        case UNETMI_ACT_RELU: return fmaxf(u, 0.f);
+        case UNETMI_ACT_SILU: return u / (1.f + expf(-u));
+        case UNETMI_ACT_SOFTPLUS: return u > 20.f ? u : log1pf(expf(u));
+        case UNETMI_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
+        case UNETMI_ACT_TANH: return tanhf(u);
+        case UNETMI_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+        default: return u;
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void glu_kernel(const void* __restrict__ z, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, const float* __restrict__ act_param,
+                                                  const float* __restrict__ gate, void* __restrict__ out, int K, int HW,
+                                                  int act) {
+    const int nk = blockIdx.y, n = nk / K, k = nk - n * K;
+    const float sc = scale ? scale[k] : 1.f, sh = shift ? shift[k] : 0.f;
+    const float ap = act_param ? act_param[0] : 0.f, g = gate ? gate[nk] : 1.f;
+    const size_t c_off = ((size_t)n * 2 * K + k) * HW, m_off = c_off + (size_t)K * HW, o_off = (size_t)nk * HW;
+    const int base = blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = base + j * 256;
+        if (i < HW) {
+            const float c = ld_act<BF16>(z, c_off + i), m = ld_act<BF16>(z, m_off + i);
+            const float v = c * (1.f / (1.f + expf(-m)));
+            st_act<BF16>(out, o_off + i, g * glu_act(act, fmaf(v, sc, sh), ap));
+        }
+    }
+}
+
 // Complex ratio filter: Y[b,n,c,f,t] = sum_{p,q} Hf[b,n,c,p,q,f,t] * X[b,c,f+p-Lf,t+q-Lt]  (zero outside).
 // All tensors complex64 viewed as float2; one thread per output element, t innermost.
 __global__ __launch_bounds__(256) void crf_apply_kernel(const float2* __restrict__ Hf, const float2* __restrict__ X,
@@ -174,6 +210,24 @@ int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const vo
                            y, x, out, K, Cx, (size_t)F * T, total, eps);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("tanh_mask launch: ") + hipGetErrorString(e));
+}
+
+int unetmi_glu_fwd(int N, int K, int HW, const void* z, const float* scale, const float* shift, int act,
+                   const float* act_param, const float* gate, void* out, int dtype, void* stream) {
+    if (N < 0 || K < 1 || HW < 1) return api_fail(UNETMI_E_BAD_DESC, "glu: bad sizes");
+    if (act < UNETMI_ACT_NONE || act > UNETMI_ACT_GELU) return api_fail(UNETMI_E_BAD_DESC, "glu: unknown activation");
+    if (N == 0) return UNETMI_OK;
+    if (!z || !out) return api_fail(UNETMI_E_BAD_ARG, "glu: null tensor pointer");
+    if (act == UNETMI_ACT_LEAKY && !act_param) return api_fail(UNETMI_E_BAD_ARG, "glu: LeakyReLU / PReLU needs its slope");
+    if ((long long)N * K > 65535) return api_fail(UNETMI_E_UNSUPPORTED, "glu: N*K > 65535");
+    const dim3 grid((HW + 1023) / 1024, N * K);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == UNETMI_DTYPE_BF16)
+        hipLaunchKernelGGL(glu_kernel<true>, grid, dim3(256), 0, s, z, scale, shift, act_param, gate, out, K, HW, act);
+    else
+        hipLaunchKernelGGL(glu_kernel<false>, grid, dim3(256), 0, s, z, scale, shift, act_param, gate, out, K, HW, act);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("glu launch: ") + hipGetErrorString(e));
 }
 
 int unetmi_crf_apply(int B, int N, int C, int PF, int PT, int F, int T, const float* Hf, const float* X, float* Y,

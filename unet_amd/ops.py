@@ -161,6 +161,7 @@ _LIBRARY.define("dwconv2d_fwd(Tensor x, Tensor? x2, Tensor weight, Tensor? bias,
 _LIBRARY.define("layernorm_f(Tensor x, Tensor gamma, Tensor beta, float eps, Tensor(a!) out, int c_off) -> ()")
 _LIBRARY.define("tanh_mask_mul(Tensor y, Tensor x, float eps) -> Tensor")
 _LIBRARY.define("crf_apply(Tensor H, Tensor X) -> Tensor")
+_LIBRARY.define("glu(Tensor z, Tensor? scale, Tensor? shift, int act, Tensor? act_param, Tensor? gate) -> Tensor")
 _LIBRARY.define("pwconv64(Tensor x, Tensor? x2, Tensor weight, Tensor? bias, Tensor scale, Tensor shift, Tensor? slope, "
                 "bool act_first, bool residual) -> Tensor")
 _LIBRARY.define("resblock_layer(Tensor x, Tensor? x2, Tensor dw_weight, Tensor? dw_bias, Tensor pw_weight, "
@@ -276,6 +277,27 @@ def _pwconv64_cuda(x, x2, weight, bias, scale, shift, slope, act_first, residual
 
 
 _LIBRARY.impl("resblock_layer", _resblock_layer_cuda, "CUDA")
+def _glu_cuda(z, scale, shift, act, act_param, gate):
+    code = dtype_code(z)
+    _dev(z, "z", "glu", z.dtype)
+    N, K2 = z.shape[0], z.shape[1]
+    if K2 % 2:
+        raise ValueError("unetmi::glu: z needs an even number of channels (features, then mask logits)")
+    K = K2 // 2
+    HW = z.numel() // max(N * K2, 1)
+    for t, name, numel in ((scale, "scale", K), (shift, "shift", K), (act_param, "act_param", 1), (gate, "gate", N * K)):
+        if t is not None:
+            _dev(t, name, "glu")
+            if t.numel() != numel:
+                raise ValueError("unetmi::glu: {} has {} elements, expected {}".format(name, t.numel(), numel))
+    out = torch.empty((N, K) + tuple(z.shape[2:]), dtype=z.dtype, device=z.device)
+    with torch.cuda.device(z.device):
+        check(_lib.lib.unetmi_glu_fwd(N, K, HW, _ptr(z), _ptr(scale), _ptr(shift), act, _ptr(act_param), _ptr(gate),
+                                      _ptr(out), code, _stream(z)), "unetmi_glu_fwd")
+    return out
+
+
+_LIBRARY.impl("glu", _glu_cuda, "CUDA")
 _LIBRARY.impl("pwconv64", _pwconv64_cuda, "CUDA")
 _LIBRARY.impl("dwconv2d_fwd", _dwconv2d_fwd_cuda, "CUDA")
 _LIBRARY.impl("layernorm_f", _layernorm_f_cuda, "CUDA")
@@ -286,6 +308,11 @@ _LIBRARY.impl("crf_apply", _crf_apply_cuda, "CUDA")
 @torch.library.register_fake("unetmi::dwconv2d_fwd")
 def _(x, x2, weight, bias, padding, dilation):
     return torch.empty_like(x)
+
+
+@torch.library.register_fake("unetmi::glu")
+def _(z, scale, shift, act, act_param, gate):
+    return z.new_empty((z.shape[0], z.shape[1] // 2) + tuple(z.shape[2:]))
 
 
 @torch.library.register_fake("unetmi::pwconv64")
@@ -314,3 +341,4 @@ tanh_mask_mul = torch.ops.unetmi.tanh_mask_mul
 crf_apply = torch.ops.unetmi.crf_apply
 resblock_layer = torch.ops.unetmi.resblock_layer
 pwconv64 = torch.ops.unetmi.pwconv64
+glu = torch.ops.unetmi.glu

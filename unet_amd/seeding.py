@@ -70,7 +70,7 @@ def seeded_fill_(module, seed=0):
     because a block sums five such layers onto its running value and twelve blocks in a
     row would otherwise grow the activations by ~4x each (saturating ResUNet's tanh
     mask completely, which would leave a parity test nothing but signs to compare).  PReLU slope
-    U(0.1, 0.4).  LSTM: U(-k, k), k = 1/sqrt(hidden).
+    U(0.1, 0.4).  LSTM / GRU: U(-k, k), k = 1/sqrt(hidden).
     Shared tensors (one PReLU registered under several names) are written once.
     """
     done = set()
@@ -114,7 +114,7 @@ def seeded_fill_(module, seed=0):
                 put(m.running_var, mname + ".running_var", 0.5, 1.5)
         elif isinstance(m, nn.PReLU):
             put(m.weight, mname + ".weight", 0.1, 0.4)
-        elif isinstance(m, nn.LSTM):
+        elif isinstance(m, (nn.LSTM, nn.GRU)):
             k = 1.0 / math.sqrt(m.hidden_size)
             for pname, p in m.named_parameters():
                 put(p, mname + "." + pname, -k, k)
