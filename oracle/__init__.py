@@ -17,14 +17,14 @@ oracle where the reference checkout is absent (the GPU box).
 
 from .blocks import (Encoder, Decoder, ResBlock, DSEncoder, DSDecoder, Attractor,
                      AttractEncoder, CRM, CRM_sig, CRM_soft, CM, GConv, TrGConv, TGRUBlock, SEBlock)
-from .nets import UNet, UNet20, ResUNet, DSUNet
+from .nets import UNet, UNet20, ResUNet, ResUNetOnFreq, DSUNet
 from .tables import unet20_layers, default_unet, dsunet_architecture
 from .masking import crf_apply, resunet_mask_apply, crm_apply
 from .helper import DSUNet_helper
 
 __all__ = [
     "Encoder", "Decoder", "ResBlock", "DSEncoder", "DSDecoder", "Attractor",
-    "AttractEncoder", "CRM", "CRM_sig", "CRM_soft", "CM", "GConv", "TrGConv", "TGRUBlock", "SEBlock", "UNet", "UNet20", "ResUNet", "DSUNet",
+    "AttractEncoder", "CRM", "CRM_sig", "CRM_soft", "CM", "GConv", "TrGConv", "TGRUBlock", "SEBlock", "UNet", "UNet20", "ResUNet", "ResUNetOnFreq", "DSUNet",
     "unet20_layers", "default_unet", "dsunet_architecture",
     "crf_apply", "resunet_mask_apply", "crm_apply", "DSUNet_helper",
 ]

@@ -196,6 +196,82 @@ class ResUNet(nn.Module):
         return torch.mul(mask, input[:, :2, :, :])
 
 
+class ResUNetOnFreq(nn.Module):
+    """30-channel variant whose strided convolutions are (3,1): frequency is halved per block, the
+    time axis is only touched by the ResBlocks' dilated depthwise taps and the LSTM.  One input
+    branch, ``n_block`` down blocks, LSTM(192, 300, 3, proj 192), a one-channel transposed output
+    layer and a Softplus / Sigmoid mask that is returned as it is.  Restates ResUNet.py:227-389.
+
+    With the shipped kernel table the frequency sizes only line up for n_block = 5 at 257 bins."""
+
+    def __init__(self, c_in=4, c_out=1, n_fft=512, device="cuda:0", print_shape=False, T=125,
+                 n_block=5, activation="Softplus", Softplus_thr=20, norm="BatchNorm2d", dropout=0.0):
+        super().__init__()
+        n_hfft = int(n_fft / 2 + 1)
+        self.print_shape = print_shape
+        self.F, self.T = n_hfft, T
+        W = 30
+        if n_block < 2:
+            raise Exception("ERROR::ResUnetOnFreq : n_block({}) < 2".format(n_block))
+        kw = dict(activation="PReLU", norm=norm)
+
+        self.layer_input = nn.Sequential(Encoder(c_in, W, (1, 3), 1, (0, 1), 1), nn.LayerNorm(n_hfft))
+
+        self.encoders = [ResBlock(W)]
+        for _ in range(n_block):  # ResUNet.py:267-271
+            self.encoders.append(nn.Sequential(Encoder(W, W, (3, 1), (2, 1), (0, 0), **kw), ResBlock(30)))
+        self.encoders.append(Encoder(W, 64, (3, 1), (2, 1), (0, 0), **kw))
+        self.encoders.append(Encoder(64, 192, (3, 1), (1, 1), (0, 0), **kw))
+        for i, m in enumerate(self.encoders):
+            self.add_module("enc_{}".format(i), m)
+
+        def up(kh):  # ResUNet.py:288-300
+            return nn.Sequential(ResBlock(W), Decoder(W, W, (kh, 1), (2, 1), (1, 0),
+                                                      output_padding=(1, 0), **kw))
+
+        self.decoders = [Decoder(192, 64, (3, 1), (1, 1), (0, 0), **kw),
+                         Decoder(64, W, (4, 1), (2, 1), (1, 0), output_padding=(1, 0), **kw)]
+        self.decoders += [up(4) for _ in range(n_block - 2)] + [up(5), up(4), ResBlock(W)]
+        for i, m in enumerate(self.decoders):
+            self.add_module("dec_{}".format(i), m)
+        self.len_model = len(self.encoders)
+
+        widths = [W] * (n_block + 1) + [64, 192]  # ResUNet.py:310-315
+        self.res_paths = [Encoder(w, w, 1, 1, 0, 1, activation="PReLU") for w in widths]
+        for i, m in enumerate(self.res_paths):
+            self.add_module("res_path_{}".format(i), m)
+
+        self.bottleneck = nn.LSTM(192, 300, 3, batch_first=True, proj_size=192, dropout=dropout)
+        self.out_layer = nn.ConvTranspose2d(W, c_out, (3, 1), stride=1, padding=(1, 0),
+                                            dilation=1, output_padding=(0, 0))
+        if activation == "Softplus":
+            self.activation_mask = nn.Softplus(threshold=Softplus_thr)
+        elif activation == "Sigmoid":
+            self.activation_mask = nn.Sigmoid()
+        else:
+            self.activation_mask = nn.Softplus()
+
+    def forward(self, input):
+        feat = self.layer_input(torch.permute(input, (0, 1, 3, 2)))
+        x = torch.permute(feat, (0, 1, 3, 2))
+        res = []
+        for enc in self.encoders:
+            x = enc(x)
+            res.append(x)
+        x = torch.reshape(x, (x.shape[0], x.shape[1], x.shape[3]))
+        x = self.bottleneck(torch.permute(x, (0, 2, 1)))[0]
+        x = torch.permute(x, (0, 2, 1))
+        y = torch.reshape(x, (x.shape[0], x.shape[1], 1, x.shape[2]))
+        for i, rp in enumerate(self.res_paths):
+            res[i] = rp(res[i])
+        for i, dec in enumerate(self.decoders):
+            y = dec(torch.add(y, res[-1 - i]))
+        return self.activation_mask(self.out_layer(y))
+
+    def output(self, mask, feature):  # ResUNet.py:388-389
+        return mask * feature[:, :2]
+
+
 class DSUNet(nn.Module):
     """Directional-separating U-Net built from an external architecture dict
     (keys ``encoder.enc{1..L}`` / ``decoder.dec{L..1}``); each encoder output is

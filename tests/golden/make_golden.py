@@ -213,6 +213,22 @@ def main():
     if out is not None:
         save("resunet_eval", out=y_ref.numpy())
 
+    print("ResUNetOnFreq as shipped (Softplus and Sigmoid masks), B=2 F=257 T=16")
+    for label, kw in (("softplus", {}), ("sigmoid", dict(activation="Sigmoid", c_in=6))):
+        ref = R_res.ResUNetOnFreq(**kw)
+        seeded_fill_(ref, seed=33)
+        mine = oracle.ResUNetOnFreq(**kw)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+        x = normal("resunet_onfreq/x_" + label, (2, kw.get("c_in", 4), 257, 16), seed=33)
+        ref.eval(), mine.eval()
+        with torch.no_grad():
+            y_ref, y_mine = ref(x), mine(x)
+        require_equal(y_ref, y_mine, "ResUNetOnFreq eval " + label)
+        assert tuple(y_ref.shape) == (2, 1, 257, 16)
+        if out is not None:
+            save("resunet_onfreq_eval_" + label, out=y_ref.numpy())
+
     print("UNet_m.ResBlock(16), B=2 F=9 T=40 (eval and train)")
     ref = R_m.ResBlock(16)
     seeded_fill_(ref, seed=32)
@@ -316,6 +332,15 @@ def main():
         facts["ResBlock_GELU"] = "ok"
     except Exception as e:  # noqa: BLE001
         facts["ResBlock_GELU"] = type(e).__name__
+    # ResUNetOnFreq2 does not run as shipped, whichever bottleneck it is built with
+    for bn_kind in ("LSTM", "GRU", "None"):
+        try:
+            net = R_res.ResUNetOnFreq2(bottleneck=bn_kind).eval()
+            with torch.no_grad():
+                net(torch.zeros(1, 1, 257, 16))
+            facts["ResUNetOnFreq2_" + bn_kind] = "ok"
+        except Exception as e:  # noqa: BLE001
+            facts["ResUNetOnFreq2_" + bn_kind] = type(e).__name__
     print("  ", facts)
     assert facts["UNet_without_global"] == "NameError" and facts["UNet10"] == "TypeError"
     print("all oracle-vs-reference checks passed")

@@ -108,6 +108,30 @@ def test_resunet_matches_golden_and_oracle(device):
     assert_close(got, torch.from_numpy(load_golden("resunet_eval")["out"]), what="ResUNet HIP vs golden")
 
 
+def test_resunet_onfreq_matches_golden_and_oracle(device):
+    """ResUNetOnFreq (30 channels, (3,1) strided convolutions, LSTM(192,300,proj 192), one-channel mask):
+    Softplus and Sigmoid heads fused into the output layer, a Softplus with another threshold run as the module."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    for label, kw in (("softplus", {}), ("sigmoid", dict(activation="Sigmoid", c_in=6)),
+                      ("thr5", dict(Softplus_thr=5))):
+        ref = oracle.ResUNetOnFreq(**kw).eval()
+        unet_amd.seeded_fill_(ref, seed=33)
+        dev = unet_amd.ResUNetOnFreq(**kw)
+        dev.load_state_dict(ref.state_dict(), strict=True)
+        x = normal("resunet_onfreq/x_" + ("softplus" if label == "thr5" else label), (2, kw.get("c_in", 4), 257, 16), seed=33)
+        with torch.no_grad():
+            want = ref(x)
+            got = dev.eval().to(device)(x.to(device))
+        assert tuple(got.shape) == (2, 1, 257, 16)
+        assert_close(got, want, what="ResUNetOnFreq {} HIP vs oracle".format(label))
+        if label != "thr5":
+            assert_close(got, torch.from_numpy(load_golden("resunet_onfreq_eval_" + label)["out"]),
+                         what="ResUNetOnFreq {} HIP vs golden".format(label))
+        assert_close(dev.output(got, x.to(device)), ref.output(want, x), what="ResUNetOnFreq.output")
+
+
 def test_pointwise_kernels(device):
     """LayerNorm over frequency, tanh mask, complex ratio filter (3x3 taps) and the
     complex-mask product, each against its CPU restatement."""

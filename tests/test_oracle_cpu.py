@@ -96,6 +96,18 @@ def test_resunet_and_resblock_match_golden():
     assert_close(y, torch.from_numpy(load_golden("resblock_eval")["out"]), tol=CPU_TOL, what="ResBlock")
 
 
+def test_resunet_onfreq_matches_golden():
+    for label, kw in (("softplus", {}), ("sigmoid", dict(activation="Sigmoid", c_in=6))):
+        net = oracle.ResUNetOnFreq(**kw).eval()
+        seeded_fill_(net, seed=33)
+        x = normal("resunet_onfreq/x_" + label, (2, kw.get("c_in", 4), 257, 16), seed=33)
+        with torch.no_grad():
+            y = net(x)
+        assert tuple(y.shape) == (2, 1, 257, 16)
+        assert_close(y, torch.from_numpy(load_golden("resunet_onfreq_eval_" + label)["out"]), tol=CPU_TOL,
+                     what="ResUNetOnFreq " + label)
+
+
 def test_dsunet_matches_golden():
     net = oracle.DSUNet(oracle.dsunet_architecture(45, 8)).eval()
     seeded_fill_(net, seed=41)

@@ -22,6 +22,43 @@ from .lstm import lstm_forward, supported as lstm_supported
 from .ops import layernorm_f, tanh_mask_mul
 
 
+def _trunk(net, x):
+    """Encoders, projected-LSTM bottleneck, 1x1 res-paths and the additive-skip decoders shared by
+    ResUNet and ResUNetOnFreq (ResUNet.py:176-215 == ResUNet.py:344-381)."""
+    res = []
+    for i, enc in enumerate(net.encoders):
+        x = enc(x)
+        if net.print_shape:
+            print("x_{} : {}".format(i, x.shape))
+        res.append(x)
+
+    # [B,C,1,T] -> [B,T,C] -> projected LSTM -> [B,C,1,T]: one persistent launch per layer for the
+    # recurrence (unet_amd/lstm.py); an LSTM of another shape runs torch's device implementation
+    seq = x.reshape(x.shape[0], x.shape[1], x.shape[3]).permute(0, 2, 1)
+    if lstm_supported(net.bottleneck):
+        seq = lstm_forward(net.bottleneck, seq.float(), net._lstm_cache).to(x.dtype)
+    else:
+        seq = net.bottleneck(seq)[0]
+    y = seq.permute(0, 2, 1).reshape(x.shape[0], x.shape[1], 1, x.shape[3]).contiguous()
+
+    for i, rp in enumerate(net.res_paths):
+        res[i] = rp(res[i])
+
+    for i, dec in enumerate(net.decoders):
+        skip = res[-1 - i]
+        if net.print_shape:
+            print("y {} += r_{} : {}".format(y.shape, i, skip.shape))
+        if isinstance(dec, Decoder):
+            y = dec(y, skip, add=True)                 # y + res read as two kernel inputs
+        elif isinstance(dec, ResBlock):
+            y = dec(y, add=skip)
+        else:                                          # Sequential(ResBlock, Decoder)
+            y = dec[1](dec[0](y, add=skip))
+        if net.print_shape:
+            print("y_{} : {}".format(i, y.shape))
+    return y
+
+
 class ResUNet(nn.Module):
     def __init__(self, c_in=4, c_out=1, n_fft=512, device="cuda:0", output="mapping", print_shape=False, T=125):
         super().__init__()
@@ -79,37 +116,7 @@ class ResUNet(nn.Module):
         self._input_branch(self.layer_data, "_in_data", input[:, :-2].contiguous(), x, 0)
         self._input_branch(self.layer_AF, "_in_af", input[:, -2:].contiguous(), x, 20)
 
-        res = []
-        for i, enc in enumerate(self.encoders):
-            x = enc(x)
-            if self.print_shape:
-                print("x_{} : {}".format(i, x.shape))
-            res.append(x)
-
-        # [B,C,1,T] -> [B,T,C] -> projected LSTM -> [B,C,1,T]: one persistent launch per layer for the
-        # recurrence (unet_amd/lstm.py); an LSTM of another shape runs torch's device implementation
-        seq = x.reshape(x.shape[0], x.shape[1], x.shape[3]).permute(0, 2, 1)
-        if lstm_supported(self.bottleneck):
-            seq = lstm_forward(self.bottleneck, seq.float(), self._lstm_cache).to(x.dtype)
-        else:
-            seq = self.bottleneck(seq)[0]
-        y = seq.permute(0, 2, 1).reshape(x.shape[0], x.shape[1], 1, x.shape[3]).contiguous()
-
-        for i, rp in enumerate(self.res_paths):
-            res[i] = rp(res[i])
-
-        for i, dec in enumerate(self.decoders):
-            skip = res[-1 - i]
-            if self.print_shape:
-                print("y {} += r_{} : {}".format(y.shape, i, skip.shape))
-            if isinstance(dec, Decoder):
-                y = dec(y, skip, add=True)                 # y + res read as two kernel inputs
-            elif isinstance(dec, ResBlock):
-                y = dec(y, add=skip)
-            else:                                          # Sequential(ResBlock, Decoder)
-                y = dec[1](dec[0](y, add=skip))
-            if self.print_shape:
-                print("y_{} : {}".format(i, y.shape))
+        y = _trunk(self, x)
 
         if self._out is None:
             object.__setattr__(self, "_out", FusedConv(self.out_layer))
@@ -118,3 +125,84 @@ class ResUNet(nn.Module):
             # on widened tensors and only the final product is rounded
             return tanh_mask_mul(self._out(y.float()), input.float().contiguous(), 1e-13).to(y.dtype)
         return tanh_mask_mul(self._out(y), input.contiguous(), 1e-13)
+
+
+class ResUNetOnFreq(nn.Module):
+    """Device ``ResUNetOnFreq`` (ResUNet.py:227-389): the 30-channel variant whose strided
+    convolutions are (3,1) and whose forward returns the mask itself.
+
+    Same launches as ``ResUNet`` with one input branch; the 30-channel ResBlocks take the
+    depthwise + pointwise launches (the one-launch-per-layer kernel is the 64-channel one) and
+    ``nn.LSTM(192, 300, 3, proj_size=192)`` is not the shape the recurrence kernel holds, so it
+    runs torch's device LSTM.  The mask activation is fused into the output layer when the
+    epilogue has it (Sigmoid, Softplus at threshold 20); another threshold runs the module.
+    """
+
+    def __init__(self, c_in=4, c_out=1, n_fft=512, device="cuda:0", print_shape=False, T=125,
+                 n_block=5, activation="Softplus", Softplus_thr=20, norm="BatchNorm2d", dropout=0.0):
+        super().__init__()
+        n_hfft = int(n_fft / 2 + 1)
+        self.print_shape = print_shape
+        self.F, self.T = n_hfft, T
+        W = 30
+        if n_block < 2:
+            raise Exception("ERROR::ResUnetOnFreq : n_block({}) < 2".format(n_block))
+        kw = dict(activation="PReLU", norm=norm)
+        self.layer_input = nn.Sequential(Encoder(c_in, W, (1, 3), 1, (0, 1), 1), nn.LayerNorm(n_hfft))
+
+        self.encoders = [ResBlock(W)]
+        self.encoders += [nn.Sequential(Encoder(W, W, (3, 1), (2, 1), (0, 0), **kw), ResBlock(30))
+                          for _ in range(n_block)]
+        self.encoders += [Encoder(W, 64, (3, 1), (2, 1), (0, 0), **kw),
+                          Encoder(64, 192, (3, 1), (1, 1), (0, 0), **kw)]
+        for i, m in enumerate(self.encoders):
+            self.add_module("enc_{}".format(i), m)
+
+        def up(kh):
+            return nn.Sequential(ResBlock(W), Decoder(W, W, (kh, 1), (2, 1), (1, 0), output_padding=(1, 0), **kw))
+
+        self.decoders = [Decoder(192, 64, (3, 1), (1, 1), (0, 0), **kw),
+                         Decoder(64, W, (4, 1), (2, 1), (1, 0), output_padding=(1, 0), **kw)]
+        self.decoders += [up(4) for _ in range(n_block - 2)] + [up(5), up(4), ResBlock(W)]
+        for i, m in enumerate(self.decoders):
+            self.add_module("dec_{}".format(i), m)
+        self.len_model = len(self.encoders)
+
+        self.res_paths = [Encoder(w, w, 1, 1, 0, 1, activation="PReLU") for w in [W] * (n_block + 1) + [64, 192]]
+        for i, m in enumerate(self.res_paths):
+            self.add_module("res_path_{}".format(i), m)
+
+        self.bottleneck = nn.LSTM(192, 300, 3, batch_first=True, proj_size=192, dropout=dropout)
+        self.out_layer = nn.ConvTranspose2d(W, c_out, (3, 1), stride=1, padding=(1, 0), dilation=1,
+                                            output_padding=(0, 0))
+        if activation == "Softplus":
+            self.activation_mask = nn.Softplus(threshold=Softplus_thr)
+        elif activation == "Sigmoid":
+            self.activation_mask = nn.Sigmoid()
+        else:
+            self.activation_mask = nn.Softplus()
+        self._in = self._out = None
+        self._lstm_cache = {}
+
+    def forward(self, input):
+        require_device_tensor(input, "ResUNetOnFreq")
+        if self.training:
+            raise NotImplementedError("ResUNetOnFreq: train-mode forward is not available in this build; call .eval()")
+        B, _, F, T = input.shape
+        x = torch.empty((B, 30, F, T), dtype=input.dtype, device=input.device)
+        ResUNet._input_branch(self, self.layer_input, "_in", input.contiguous(), x, 0)
+        y = _trunk(self, x)
+        if self._out is None:
+            from .fused import activation_code
+            fusable = activation_code(self.activation_mask) is not None
+            object.__setattr__(self, "_out", (FusedConv(self.out_layer, None, self.activation_mask if fusable else None),
+                                              fusable))
+        head, fused_act = self._out
+        # the mask comes out of a thin layer: keep it in fp32 whatever the storage type of the trunk
+        m = head(y.float() if y.dtype != torch.float32 else y)
+        if not fused_act:
+            m = self.activation_mask(m)
+        return m.to(y.dtype)
+
+    def output(self, mask, feature):
+        return mask * feature[:, :2]

@@ -11,9 +11,10 @@ from .UNet_m import Encoder, Decoder, ResBlock
 from .UNet import UNet, default_unet_blocks
 from .cRFUNet import UNet20, UNet10
 from .DSUNet import DSUNet, DSUNet_helper
-from .ResUNet import ResUNet
+from .ResUNet import ResUNet, ResUNetOnFreq
 from .tables import dsunet_architecture
 from .seeding import seeded_fill_
 
-__all__ = ["Encoder", "Decoder", "ResBlock", "UNet", "UNet20", "UNet10", "DSUNet", "DSUNet_helper", "ResUNet", "default_unet_blocks",
+__all__ = ["Encoder", "Decoder", "ResBlock", "UNet", "UNet20", "UNet10", "DSUNet", "DSUNet_helper", "ResUNet", "ResUNetOnFreq",
+           "default_unet_blocks",
            "dsunet_architecture", "seeded_fill_"]
