@@ -101,7 +101,7 @@ typedef struct UnetmiConvDesc {
     int32_t act_param_per_channel; /* 1: act_param has K entries, 0: one     */
     int32_t has_gate;
     int32_t has_residual;
-    int32_t reserved[3];     /* reserved[0] = UNETMI_DTYPE_* of in0 / in1 / residual / out; others 0 */
+    int32_t reserved[3];     /* reserved[0] = UNETMI_DTYPE_* of in0 / in1 / residual / out; [1], [2]: see unetmi_conv2d_b16_fwd, else 0 */
 } UnetmiConvDesc;
 
 int unetmi_version(void);
@@ -209,6 +209,29 @@ int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const vo
  * act_param [1] or null, gate [N,K] or null (DSUNet's attractor gate, DSUNet.py:599-602). */
 int unetmi_glu_fwd(int N, int K, int HW, const void* z, const float* scale, const float* shift, int act,
                    const float* act_param, const float* gate, void* out, int dtype, void* stream);
+
+/* ---- bfloat16-operand convolution on a channel-blocked layout ---------------------------------
+ * The same layers as unetmi_conv2d_fwd (Encoder / Decoder forward with the concat, eval BatchNorm,
+ * activation and DSUNet's gate fused: UNet_m.py:340-345, :379-383, DSUNet.py:86-93, :194-200, :599-602, :622)
+ * for activations kept between layers as  [N][CB][H][W][8] bfloat16,  CB = 2*ceil(C/16)  (eight
+ * consecutive channels of a pixel form one 16-byte record; channels padded with zeros to a multiple of 16).
+ * Products run on the bf16 matrix instruction with fp32 accumulation; bias / BatchNorm / activation /
+ * gate are applied to the fp32 accumulator.  Descriptor as for unetmi_conv2d_fwd, with
+ *   in_mode      UNETMI_IN_SINGLE or UNETMI_IN_CONCAT (no add, no residual), K <= 128,
+ *   reserved[1]  weight halves: 0/1 = weights rounded to bfloat16; 2 = a second image holds the rounding
+ *                remainder and a second MFMA adds it (fp32-weight accuracy at twice the matrix work),
+ *   reserved[2]  1: write out as plain fp32 NCHW [N,K,OH,OW] instead of the blocked layout (heads). */
+size_t unetmi_conv2d_b16_packed_weight_bytes(const UnetmiConvDesc* d);
+/* HOST function; w: torch-layout fp32 weight, packed: host buffer of the size above. */
+int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void* packed);
+int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
+                          const float* bias, const float* scale, const float* shift, const float* act_param,
+                          const float* gate, void* out, void* stream);
+/* Layout conversion either side of such a chain: src NCHW [N,C,HW] (UNETMI_DTYPE_*) -> blocked, and back.
+ * These have no counterpart in the reference (its tensors are NCHW throughout). */
+int unetmi_blocked_from_nchw(int N, int C, int HW, const void* src, int src_dtype, void* dst, void* stream);
+int unetmi_nchw_from_blocked(int N, int C, int HW, const void* src, void* dst, int dst_dtype, void* stream);
+
 
 /* Complex ratio filter / complex mask application over the STFT:
  *   Y[b,n,c,f,t] = sum_{p<PF, q<PT} Hf[b,n,c,p,q,f,t] * X[b,c,f+p-(PF-1)/2, t+q-(PT-1)/2]   (zero outside)

@@ -1,0 +1,129 @@
+"""bfloat16-operand convolution on the channel-blocked layout (csrc/conv_b16.hip) against the CPU
+restatement: the same layer in fp32 torch ops on the bfloat16-rounded input.
+
+Tolerances: with two weight halves (hi + rounding remainder) the products equal fp32-weight products up
+to 2^-17 relative, so the result is held to the fp32 bar of 1e-4 before the output rounding; the output
+itself is bfloat16, so the comparison is made against the reference rounded the same way, with one
+bfloat16 ulp (2^-8 relative, on the tensor's scale) of slack for values that straddle a rounding
+boundary.  With one half (weights rounded to bfloat16) the reference uses the rounded weights too.
+"""
+
+import pytest
+import torch
+import torch.nn as nn
+
+from util import rel_err
+from unet_amd._lib import UnetmiError
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+def bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def test_layout_round_trip(device):
+    from unet_amd.blocked import BlockedTensor
+    g = torch.Generator().manual_seed(1)
+    for C in (1, 8, 16, 45, 90):
+        x = torch.randn(2, C, 5, 37, generator=g)
+        for src in (x, x.to(torch.bfloat16)):
+            b = BlockedTensor.from_nchw(src.to(device))
+            assert tuple(b.data.shape) == (2, 2 * ((C + 15) // 16), 5, 37, 8)
+            assert torch.equal(b.to_nchw(torch.float32).cpu(), bf(x))
+            assert torch.equal(b.to_nchw(torch.bfloat16).cpu(), x.to(torch.bfloat16))
+            # padded channels are zero
+            flat = b.data.permute(0, 1, 4, 2, 3).reshape(2, -1, 5, 37)
+            assert flat[:, C:].abs().max().item() == 0 if flat.shape[1] > C else True
+
+
+CASES = [
+    # (C0, C1, K, kernel, stride, padding, output_padding, transposed, H, W)
+    (8, 0, 45, (7, 1), (1, 1), (3, 0), (0, 0), False, 19, 70),
+    (45, 0, 45, (1, 7), (1, 1), (0, 3), (0, 0), False, 11, 77),
+    (45, 0, 90, (7, 5), (2, 2), (3, 2), (0, 0), False, 33, 70),
+    (90, 0, 90, (7, 5), (2, 1), (3, 2), (0, 0), False, 33, 41),
+    (90, 0, 90, (5, 3), (2, 2), (2, 1), (0, 0), False, 17, 34),
+    (90, 0, 128, (5, 3), (2, 1), (2, 1), (0, 0), False, 5, 34),
+    (128, 0, 90, (5, 3), (2, 1), (2, 1), (0, 0), True, 2, 32),
+    (90, 90, 90, (5, 3), (2, 2), (2, 1), (0, 1), True, 3, 16),
+    (90, 90, 90, (7, 5), (2, 1), (3, 2), (0, 0), True, 17, 40),
+    (90, 45, 90, (7, 5), (2, 2), (3, 2), (0, 1), True, 9, 35),
+    (90, 45, 90, (1, 7), (1, 1), (0, 3), (0, 0), True, 9, 70),
+    (90, 8, 90, (7, 1), (1, 1), (3, 0), (0, 0), True, 21, 33),
+    (16, 0, 32, (3, 3), (1, 1), (1, 2), (0, 0), False, 9, 40),
+    (20, 12, 64, (3, 3), (1, 1), (1, 1), (0, 0), False, 12, 65),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "C{}+{}_K{}_k{}x{}_s{}{}_{}".format(
+    c[0], c[1], c[2], c[3][0], c[3][1], c[4][0], c[4][1], "T" if c[7] else "C"))
+@pytest.mark.parametrize("halves", [1, 2])
+def test_conv_b16_matches_cpu(device, case, halves):
+    from unet_amd.blocked import BlockedConv, BlockedTensor
+    C0, C1, K, k, s, p, op, transposed, H, W = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + halves)
+    C = C0 + C1
+    if transposed:
+        conv = nn.ConvTranspose2d(C, K, k, stride=s, padding=p, output_padding=op)
+    else:
+        conv = nn.Conv2d(C, K, k, stride=s, padding=p)
+    bn = nn.BatchNorm2d(K).eval()
+    act = nn.LeakyReLU(0.01)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (C * k[0] * k[1]) ** 0.5)
+        conv.bias.copy_(torch.randn(K, generator=g) * 0.1)
+        bn.weight.copy_(torch.rand(K, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(K, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(K, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(K, generator=g) + 0.5)
+    N = 2
+    x0 = torch.randn(N, C0, H, W, generator=g)
+    x1 = torch.randn(N, C1, H, W, generator=g) if C1 else None
+    gate = torch.rand(N, K, generator=g) + 0.25
+    with torch.no_grad():
+        xin = bf(x0) if x1 is None else torch.cat([bf(x0), bf(x1)], 1)
+        ref_conv = conv
+        if halves == 1:
+            ref_conv = type(conv)(C, K, k, stride=s, padding=p, **(dict(output_padding=op) if transposed else {}))
+            ref_conv.weight.copy_(bf(conv.weight))
+            ref_conv.bias.copy_(conv.bias)
+        want = act(bn(ref_conv(xin))) * gate[:, :, None, None]
+    layer = BlockedConv(conv, bn, act, halves=halves)
+    b0 = BlockedTensor.from_nchw(x0.to(device))
+    b1 = BlockedTensor.from_nchw(x1.to(device)) if x1 is not None else None
+    try:
+        got = layer(b0, b1, gate.to(device))
+    except UnetmiError as e:
+        # the doubled weight image of the two-half mode does not fit beside a stride-2 input image
+        assert halves == 2 and "LDS images exceed" in str(e), str(e)
+        pytest.skip("two weight halves: LDS images of this layer exceed 160 KB")
+    assert got.shape == tuple(want.shape)
+    got32 = got.to_nchw(torch.float32).cpu()
+    scale = want.abs().max().item()
+    err = (got32 - bf(want)).abs().max().item() / scale
+    assert err <= 2.0 ** -8 + 1e-4, "blocked conv vs rounded reference: {:.3e}".format(err)
+    # the unrounded accumulator path: fp32 NCHW output holds the fp32 bar
+    head = BlockedConv(conv, bn, act, halves=halves, nchw_out=True)
+    got_f32 = head(b0, b1, gate.to(device)).cpu()
+    e = rel_err(got_f32, want)
+    assert e <= 1e-4, "fp32-output blocked conv: rel-err {:.3e}".format(e)
+    # padded output channels are exact zeros (the next layer multiplies them by zero weights)
+    raw = got.data.permute(0, 1, 4, 2, 3).reshape(N, -1, *got.data.shape[2:4])
+    if raw.shape[1] > K:
+        assert raw[:, K:].float().abs().max().item() == 0.0
+
+
+def test_conv_b16_rejects(device):
+    import ctypes
+    from unet_amd import _lib
+    from unet_amd.blocked import _desc
+    d = _desc(1, 16, 0, 8, 8, [200, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0], 0, 0, 0, 0, 0, 1, False)
+    assert _lib.lib.unetmi_conv2d_b16_packed_weight_bytes(ctypes.byref(d)) == 0
+    assert "128 output channels" in _lib.last_error()

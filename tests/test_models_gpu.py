@@ -244,8 +244,10 @@ def test_resunet_bf16_storage(device):
     assert_bf16_close(got, want, "ResUNet bf16 storage")
 
 
-def test_dsunet_bf16_storage(device):
-    """DSUNet with bfloat16 activation storage against the fp32 oracle (complex64 mask out)."""
+def test_dsunet_bf16(device):
+    """DSUNet on a bfloat16 input against the fp32 oracle (complex64 mask out), both ways the package runs it:
+    bfloat16 operands on the matrix cores over the channel-blocked layout (the default), and bfloat16
+    storage with fp32 products on the NCHW kernels."""
     import oracle
     import unet_amd
     from unet_amd.seeding import normal, uniform
@@ -260,9 +262,16 @@ def test_dsunet_bf16_storage(device):
     theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
     with torch.no_grad():
         want = ref(sf.float(), SV, theta)
-        got = dev(sf.to(device), SV.to(device), theta.to(device))
-    assert got.dtype == torch.complex64
-    assert_bf16_close(got, want, "DSUNet bf16 storage")
+        for matrix in (True, False):
+            dev.bf16_matrix = matrix
+            got = dev(sf.to(device), SV.to(device), theta.to(device))
+            assert got.dtype == torch.complex64
+            what = "DSUNet bf16 " + ("operands, blocked layout" if matrix else "storage, NCHW")
+            g, w = torch.view_as_real(got.cpu()), torch.view_as_real(want)
+            print("{}: relative L2 {:.3e}, max-norm {:.3e}".format(
+                what, ((g - w).norm() / w.norm()).item(), ((g - w).abs().max() / w.abs().max()).item()))
+            assert_bf16_close(got, want, what)
+    assert dev._blocked, "the blocked bf16 path was not taken"
 
 
 @pytest.mark.parametrize("geom", [(64, 64, (3, 3), (2, 1), (0, 1), False), (64, 64, (4, 1), (2, 1), (1, 0), True),

@@ -322,11 +322,51 @@ class DSUNet(nn.Module):
         self.attractors = nn.ModuleList(self.attractEncoders)
         self.res = nn.ModuleList(res)
         self._head = None
+        self._blocked = None
+        # bfloat16 inputs: run the convolutions with bfloat16 operands on the channel-blocked layout
+        # (unet_amd/blocked.py) when every layer is one that kernel serves; False keeps the NCHW
+        # bfloat16-storage kernels (fp32 products)
+        self.bf16_matrix = True
+
+    def _blocked_layers(self):
+        """BlockedConv per encoder / decoder / head, or False when a layer is outside that kernel."""
+        if self._blocked is None:
+            from .blocked import BlockedConv
+            ok = isinstance(self.BTN, nn.Identity) and activation_code(self.mask.squash) is not None
+            for m in list(self.encoders) + list(self.decoders):
+                conv = getattr(m, "conv", None) if isinstance(m, Encoder) else getattr(m, "transconv", None)
+                ok = ok and isinstance(m, (Encoder, Decoder)) and isinstance(m.bn, nn.BatchNorm2d) and \
+                    activation_code(m.relu) is not None and conv.out_channels <= 128 and \
+                    getattr(conv, "padding_mode", "zeros") == "zeros"
+            built = False
+            if ok:
+                built = dict(enc=[BlockedConv(m.conv, m.bn, m.relu) for m in self.encoders],
+                             dec=[BlockedConv(m.transconv, m.bn, m.relu) for m in self.decoders],
+                             head=BlockedConv(self.linear, None, self.mask.squash, nchw_out=True))
+            object.__setattr__(self, "_blocked", built)
+        return self._blocked
+
+    def _forward_blocked(self, layers, sf, attract):
+        from .blocked import BlockedTensor
+        L = self.n_layer
+        x = BlockedTensor.from_nchw(sf.contiguous())
+        skips = []
+        for i, enc in enumerate(layers["enc"]):
+            skips.append(x)
+            x = enc(x, None, self.attractEncoders[i](attract).float().contiguous())
+        for i, dec in enumerate(layers["dec"]):
+            x = dec(x, None if i == 0 else skips[L - i])
+        m = layers["head"](x)                                          # fp32 [B, 2, F, T], squashed
+        return torch.complex(m[:, 0, ...], m[:, 1, ...])
 
     def forward(self, sf, SV, theta):
         require_device_tensor(sf, "DSUNet")
         attract = self.Attractor(SV.float(), theta.float())            # tiny fp32 side network, whatever sf's storage
         L = self.n_layer
+        if sf.dtype == torch.bfloat16 and self.bf16_matrix and not self.training:
+            layers = self._blocked_layers()
+            if layers:
+                return self._forward_blocked(layers, sf, attract)
         skips = []
         for i, enc in enumerate(self.encoders):
             skips.append(self.res[i](sf) if i != L - 1 else sf)

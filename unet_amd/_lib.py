@@ -37,6 +37,11 @@ EXPORTED_SYMBOLS = (
     "unetmi_pwconv64_fwd",
     "unetmi_lstm_recurrence",
     "unetmi_glu_fwd",
+    "unetmi_conv2d_b16_packed_weight_bytes",
+    "unetmi_conv2d_b16_pack_weights",
+    "unetmi_conv2d_b16_fwd",
+    "unetmi_blocked_from_nchw",
+    "unetmi_nchw_from_blocked",
 )
 
 
@@ -99,6 +104,16 @@ def _load():
     lib.unetmi_glu_fwd.argtypes = [ci] * 3 + [fp] * 3 + [ci] + [fp] * 3 + [ci, vp]
     lib.unetmi_glu_fwd.restype = ctypes.c_int
     lib.unetmi_adam_step.argtypes = [sz] + [fp] * 4 + [cf] * 6 + [ci, vp]
+    lib.unetmi_conv2d_b16_packed_weight_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+    lib.unetmi_conv2d_b16_packed_weight_bytes.restype = sz
+    lib.unetmi_conv2d_b16_pack_weights.argtypes = [ctypes.POINTER(ConvDesc), fp, fp]
+    lib.unetmi_conv2d_b16_pack_weights.restype = ctypes.c_int
+    lib.unetmi_conv2d_b16_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 9 + [vp]
+    lib.unetmi_conv2d_b16_fwd.restype = ctypes.c_int
+    lib.unetmi_blocked_from_nchw.argtypes = [ci] * 3 + [fp, ci, fp, vp]
+    lib.unetmi_blocked_from_nchw.restype = ctypes.c_int
+    lib.unetmi_nchw_from_blocked.argtypes = [ci] * 3 + [fp, fp, ci, vp]
+    lib.unetmi_nchw_from_blocked.restype = ctypes.c_int
     for f in (lib.unetmi_bn_train_stats, lib.unetmi_bn_act_fwd, lib.unetmi_bn_act_bwd, lib.unetmi_conv2d_wgrad,
               lib.unetmi_adam_step):
         f.restype = ctypes.c_int

@@ -1,0 +1,579 @@
+// Convolution / transposed convolution with bfloat16 OPERANDS on the matrix cores
+// (v_mfma_f32_32x32x16_bf16, 16x the rate of the exact-fp32 MFMA) over a
+// channel-blocked activation layout.
+//
+// Layout ("blocked"): [N][CB][H][W][8] bfloat16, CB = 2 * ceil(C / 16): eight consecutive channels
+// of one pixel are one 16-byte record, channels are padded with zeros to a multiple of 16.  That
+// is exactly what one lane of the bf16 MFMA consumes (8 consecutive K values), so a B operand is
+// ONE ds_read_b128 and an input row reaches LDS by 16-byte LDS-DMA without passing registers.
+//
+// GEMM view: M = output channels (A = weights, 32 per tile, MT tiles per wave), N = 32 * NT pixels
+// along time, K = (16-channel group, tap).  A workgroup is 8 waves = 8 output rows x 32 NT columns x
+// all output channels.  One pipeline step = (channel group, tap row): its weights [tap col][MT][32][16]
+// arrive two steps ahead in a 3-deep LDS ring, the group's input rows one group ahead (two when a
+// tap row is a whole group), so HBM / L2 latency is covered by one or two steps of MFMA work and a
+// step ends with one s_barrier and a counted vmcnt wait -- never a full drain.
+//
+// Strided and transposed layers use the same loop: every layer is a set of "phases", each a
+// stride-1 walk over its own output sub-grid with  ih = i*sih + t*tdh + offh,  oh = i*soh + poh
+// (plain conv: one phase, sih = stride, tdh = dilation; transposed: stride_h * stride_w phases with
+// sih = 1, tdh = -1 and the taps of that phase only).
+//
+// Weights are bfloat16 (rounded to nearest-even by the packer); with hl = 2 the packer also stores
+// the rounding remainder as a second bfloat16 image and the kernel issues a second MFMA with it,
+// which reproduces fp32-weight arithmetic (bf16 x bf16 products are exact in fp32).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "../../include/unetmi.h"
+#include "io_types.hpp"
+
+namespace unetmi {
+int api_fail(int code, const std::string& msg);
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float b16_f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* b16_lds_ptr;
+
+constexpr int kB16MaxPhase = 4;
+constexpr int kB16Waves = 8;          // waves (= output rows) per workgroup
+constexpr int kB16MaxQ = 8;           // input DMA instructions per wave and group (64 KB image)
+constexpr int kB16WRing = 3;
+
+struct B16Phase {
+    int nth, ntw;            // taps of this phase
+    int offh, offw;          // ih = i*sih + t*tdh + offh
+    int poh, pow_;           // oh = i*soh + poh
+    int rows, cols;          // extent of this phase's output grid
+    unsigned wg_end;         // workgroups up to and including this phase
+    unsigned w_off;          // byte offset of the phase's weight image
+    unsigned w_bytes;        // its size
+};
+
+struct B16Args {
+    const char* in0; const char* in1; const char* w;
+    const float* bias; const float* scale; const float* shift; const float* act_param; const float* gate;
+    void* out;
+    int N, H, W, OH, OW, K;
+    int G0, G1;              // 16-channel groups of the two sources
+    int sih, siw, tdh, tdw, soh, sow;
+    int nphase, hl, din;     // weight halves (1 | 2); input prefetch distance in groups (1 | 2)
+    int in_buf_bytes, w_buf_bytes;
+    int act, act_first, act_pc, out_nchw_f32;
+    B16Phase ph[kB16MaxPhase];
+};
+
+__device__ __forceinline__ float b16_act(float v, int act, float slope) {
+    switch (act) {
+        case UNETMI_ACT_LEAKY:    return v >= 0.f ? v : v * slope;
+        case UNETMI_ACT_RELU:     return fmaxf(v, 0.f);
+        case UNETMI_ACT_SILU:     return v / (1.f + expf(-v));
+        case UNETMI_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
+        case UNETMI_ACT_SIGMOID:  return 1.f / (1.f + expf(-v));
+        case UNETMI_ACT_TANH:     return tanhf(v);
+        case UNETMI_ACT_GELU:     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        default:                  return v;
+    }
+}
+
+// wait until at most n of this wave's vector-memory operations (LDS-DMA included) are outstanding
+__device__ __forceinline__ void b16_wait_vm(int n) {
+    switch (n) {
+        case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1:  asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2:  asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3:  asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5:  asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6:  asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7:  asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8:  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9:  asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, j = lane & 31;
+    const int nin_buf = p.din + 1;
+    char* const s_in = smem;
+    char* const s_w = smem + nin_buf * p.in_buf_bytes;
+    float* const s_par = reinterpret_cast<float*>(s_w + kB16WRing * p.w_buf_bytes);   // [5][MT*32]
+
+    // ---- this workgroup's phase and tile ----------------------------------------------
+    unsigned bid = blockIdx.x;
+    int a = 0;
+    unsigned start = 0;
+#pragma unroll
+    for (int q = 0; q < kB16MaxPhase - 1; ++q)
+        if (q + 1 < p.nphase && bid >= p.ph[q].wg_end) { a = q + 1; start = p.ph[q].wg_end; }
+    bid -= start;
+    const int nth = p.ph[a].nth, ntw = p.ph[a].ntw;
+    const int prow = p.ph[a].rows, pcol = p.ph[a].cols;
+    const int njt = (pcol + 32 * NT - 1) / (32 * NT), nit = (prow + kB16Waves - 1) / kB16Waves;
+    const int jt = bid % njt; bid /= njt;
+    const int it = bid % nit;
+    const int n = bid / nit;
+    const int i0 = it * kB16Waves, j0 = jt * 32 * NT;
+
+    const int spanh = (nth - 1) * p.tdh, spanw = (ntw - 1) * p.tdw;
+    const int negh = spanh < 0 ? spanh : 0, negw = spanw < 0 ? spanw : 0;
+    const int rows_in = (kB16Waves - 1) * p.sih + (spanh < 0 ? -spanh : spanh) + 1;
+    const int cols_in = (32 * NT - 1) * p.siw + (spanw < 0 ? -spanw : spanw) + 1;
+    const int plane = rows_in * cols_in;
+    const int slots = 2 * plane;
+    const int n_in_instr = (slots + 63) >> 6;
+    const int ihb = i0 * p.sih + p.ph[a].offh + negh;
+    const int iwb = j0 * p.siw + p.ph[a].offw + negw;
+    const int HW = p.H * p.W;
+
+    // ---- per-lane byte offsets of this wave's input DMA instructions (same for every group) ----
+    int voff[kB16MaxQ];
+#pragma unroll
+    for (int k = 0; k < kB16MaxQ; ++k) {
+        const int e = (wave + kB16Waves * k) * 64 + lane;
+        int off = (int)0x80000000;
+        if (e < slots) {
+            const int hf = e >= plane ? 1 : 0;
+            const int rem = e - hf * plane;
+            const int r = rem / cols_in, c = rem - r * cols_in;
+            const int ih = ihb + r, iw = iwb + c;
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) off = (hf * HW + ih * p.W + iw) * 16;
+        }
+        voff[k] = off;
+    }
+
+    const int G = p.G0 + p.G1;
+    const int step_bytes = ntw * p.hl * MT * 1024;
+    const int n_w_instr = ntw * p.hl * MT;
+    const int S = G * nth;
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + p.ph[a].w_off), 0, (int)p.ph[a].w_bytes, 0x00020000);
+
+    auto issue_input = [&](int g) -> int {            // group g -> its ring slot; returns instructions issued
+        if (g >= G) return 0;
+        const bool second = g >= p.G0;
+        const int gl = second ? g - p.G0 : g;
+        const int CB = 2 * (second ? p.G1 : p.G0);
+        const char* base = (second ? p.in1 : p.in0) + (size_t)n * CB * HW * 16;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, CB * HW * 16, 0x00020000);
+        const int soff = 2 * gl * HW * 16;
+        char* dst = s_in + (g % nin_buf) * p.in_buf_bytes;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kB16MaxQ; ++k) {
+            const int q = wave + kB16Waves * k;
+            if (q < n_in_instr) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (b16_lds_ptr)(dst + q * 1024), 16, voff[k], soff, 0, 0);
+                ++cnt;
+            }
+        }
+        return cnt;
+    };
+    auto issue_weights = [&](int s) -> int {          // step s -> ring slot s % 3
+        if (s >= S) return 0;
+        char* dst = s_w + (s % kB16WRing) * p.w_buf_bytes;
+        const int soff0 = s * step_bytes;
+        int cnt = 0;
+        for (int q = wave; q < n_w_instr; q += kB16Waves) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (b16_lds_ptr)(dst + q * 1024), 16, lane * 16, soff0 + q * 1024, 0, 0);
+            ++cnt;
+        }
+        return cnt;
+    };
+
+    // ---- prologue: epilogue parameters and the first steps' operands --------------------------
+    if (tid < MT * 32) {
+        float par[5] = {0.f, 0.f, 0.f, 0.f, 0.f};       // channels past K produce exact zeros
+        if (tid < p.K) {
+            par[0] = p.bias[tid]; par[1] = p.scale[tid]; par[2] = p.shift[tid];
+            if (p.act_param) par[3] = p.act_param[p.act_pc ? tid : 0];
+            par[4] = p.gate ? p.gate[(size_t)n * p.K + tid] : 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) s_par[q * MT * 32 + tid] = par[q];
+    }
+    for (int g = 0; g < p.din; ++g) issue_input(g);
+    issue_weights(0);
+    issue_weights(1);
+    __syncthreads();                                   // full drain once
+
+    b16_f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    int colb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) colb[nt] = ((nt * 32 + j) * p.siw - negw) * 16;
+    const int a_lane = half * 512 + j * 16;
+
+    int s = 0;
+    for (int g = 0; g < G; ++g) {
+        const char* in_img = s_in + (g % nin_buf) * p.in_buf_bytes;
+        for (int th = 0; th < nth; ++th, ++s) {
+            int issued = issue_weights(s + 2);
+            if (th == 0) issued += issue_input(g + p.din);
+
+            const int rowl = wave * p.sih + th * p.tdh - negh;
+            const char* brow = in_img + (half * plane + rowl * cols_in) * 16;
+            const char* wimg = s_w + (s % kB16WRing) * p.w_buf_bytes + a_lane;
+#pragma unroll 1
+            for (int tw = 0; tw < ntw; ++tw) {
+                bf16x8 B[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    B[nt] = *reinterpret_cast<const bf16x8*>(brow + colb[nt] + tw * p.tdw * 16);
+                for (int h = 0; h < p.hl; ++h) {
+                    const char* wt = wimg + (tw * p.hl + h) * MT * 1024;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+            // everything issued before this step has to have landed; this step's own loads may fly on
+            b16_wait_vm(__builtin_amdgcn_readfirstlane(issued));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    const int i = i0 + wave;
+    if (i >= prow) return;                              // wave-uniform
+    const int oh = i * p.soh + p.ph[a].poh;
+    const int CBo = 2 * ((p.K + 15) >> 4);
+    const size_t OHW = (size_t)p.OH * p.OW;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int jc = j0 + nt * 32 + j;
+        if (jc >= pcol) continue;
+        const int ow = jc * p.sow + p.ph[a].pow_;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mt * 32 + q * 8 + half * 4 + r;
+                    float x = acc[mt][nt][q * 4 + r] + s_par[m];
+                    const float sc = s_par[MT * 32 + m], sf = s_par[2 * MT * 32 + m], sl = s_par[3 * MT * 32 + m];
+                    if (p.act_first) x = b16_act(x, p.act, sl) * sc + sf;
+                    else             x = b16_act(x * sc + sf, p.act, sl);
+                    v[r] = x * s_par[4 * MT * 32 + m];
+                }
+                const int blk = mt * 4 + q;
+                if (p.out_nchw_f32) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = blk * 8 + half * 4 + r;
+                        if (m < p.K) static_cast<float*>(p.out)[((size_t)n * p.K + m) * OHW + (size_t)oh * p.OW + ow] = v[r];
+                    }
+                } else if (blk < CBo) {
+                    uint2 w2;
+                    w2.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                    w2.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                    char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + (size_t)oh * p.OW + ow) * 16 + half * 8;
+                    *reinterpret_cast<uint2*>(o) = w2;
+                }
+            }
+    }
+}
+
+// ---- layout conversion ------------------------------------------------------------------------
+// NCHW (fp32 or bfloat16) -> blocked; a thread owns one pixel of one 8-channel block.
+template <bool SRC_BF16>
+__global__ __launch_bounds__(256) void to_blocked_kernel(const void* src, char* dst, int C, int CB, int HW) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int blk = blockIdx.y, n = blockIdx.z;
+    if (pix >= HW) return;
+    unsigned short v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = blk * 8 + k;
+        v[k] = c < C ? f32_to_bf16_bits(ld_act<SRC_BF16>(src, ((size_t)n * C + c) * HW + pix)) : (unsigned short)0;
+    }
+    uint4 o;
+    o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
+    o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+    *reinterpret_cast<uint4*>(dst + (((size_t)n * CB + blk) * HW + pix) * 16) = o;
+}
+
+template <bool DST_BF16>
+__global__ __launch_bounds__(256) void from_blocked_kernel(const char* src, void* dst, int C, int CB, int HW) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int blk = blockIdx.y, n = blockIdx.z;
+    if (pix >= HW) return;
+    const uint4 o = *reinterpret_cast<const uint4*>(src + (((size_t)n * CB + blk) * HW + pix) * 16);
+    const unsigned w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = blk * 8 + k;
+        if (c >= C) continue;
+        const unsigned short b = (unsigned short)(k & 1 ? w[k >> 1] >> 16 : w[k >> 1] & 0xffffu);
+        st_act<DST_BF16>(dst, ((size_t)n * C + c) * HW + pix, bf16_bits_to_f32(b));
+    }
+}
+
+// ---- host: plan, packer, launch ---------------------------------------------------------------
+struct B16Plan {
+    B16Args args;
+    int MT, NT;
+    unsigned grid;
+    size_t lds_bytes, packed_bytes;
+    int kh0[kB16MaxPhase], kw0[kB16MaxPhase], khs, kws;      // kernel index of tap t: k0 + t * ks
+};
+
+static unsigned short host_bf16(float v) {
+    unsigned u;
+    std::memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float host_bf16_to_f32(unsigned short b) {
+    const unsigned u = (unsigned)b << 16;
+    float v;
+    std::memcpy(&v, &u, 4);
+    return v;
+}
+
+static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err) {
+    auto bad = [&](const char* m) { *err = m; return false; };
+    if (d.N < 0 || d.C0 < 1 || d.C1 < 0 || d.H < 1 || d.W < 1 || d.K < 1 || d.kh < 1 || d.kw < 1 || d.sh < 1 || d.sw < 1 ||
+        d.dh < 1 || d.dw < 1 || d.ph < 0 || d.pw < 0)
+        return bad("conv2d_b16: bad sizes");
+    if (d.in_mode != UNETMI_IN_SINGLE && d.in_mode != UNETMI_IN_CONCAT) return bad("conv2d_b16: in_mode must be single or concat");
+    if (d.in_mode == UNETMI_IN_SINGLE && d.C1 != 0) return bad("conv2d_b16: C1 must be 0 for a single input");
+    if (d.has_residual) return bad("conv2d_b16: no residual input");
+    const int hl = d.reserved[1] == 0 ? 1 : d.reserved[1];
+    if (hl != 1 && hl != 2) return bad("conv2d_b16: reserved[1] (weight halves) must be 0, 1 or 2");
+    int OH, OW;
+    if (d.transposed) {
+        if ((d.sh > 1 && d.dh != 1) || (d.sw > 1 && d.dw != 1)) return bad("conv2d_b16: strided transposed conv needs dilation 1");
+        OH = (d.H - 1) * d.sh - 2 * d.ph + d.dh * (d.kh - 1) + d.oph + 1;
+        OW = (d.W - 1) * d.sw - 2 * d.pw + d.dw * (d.kw - 1) + d.opw + 1;
+    } else {
+        OH = (d.H + 2 * d.ph - d.dh * (d.kh - 1) - 1) / d.sh + 1;
+        OW = (d.W + 2 * d.pw - d.dw * (d.kw - 1) - 1) / d.sw + 1;
+    }
+    if (OH != d.OH || OW != d.OW || OH < 1 || OW < 1) return bad("conv2d_b16: OH/OW do not match the geometry");
+    B16Args& a = pl->args;
+    std::memset(&a, 0, sizeof(a));
+    a.N = d.N; a.H = d.H; a.W = d.W; a.OH = OH; a.OW = OW; a.K = d.K;
+    a.G0 = (d.C0 + 15) / 16; a.G1 = (d.C1 + 15) / 16;
+    a.hl = hl;
+    a.act = d.act; a.act_first = d.act_first; a.act_pc = d.act_param_per_channel; a.out_nchw_f32 = d.reserved[2] != 0;
+    pl->MT = (d.K + 31) / 32;
+    if (pl->MT > 4) return bad("conv2d_b16: more than 128 output channels");
+    if ((size_t)2 * std::max(a.G0, a.G1) * d.H * d.W * 16 >= (size_t)1 << 31) return bad("conv2d_b16: sample larger than 2 GB");
+    int np = 0;
+    bool single_row_group = false;
+    if (!d.transposed) {
+        a.sih = d.sh; a.siw = d.sw; a.tdh = d.dh; a.tdw = d.dw; a.soh = 1; a.sow = 1;
+        B16Phase& p = a.ph[0];
+        p.nth = d.kh; p.ntw = d.kw; p.offh = -d.ph; p.offw = -d.pw; p.poh = 0; p.pow_ = 0; p.rows = OH; p.cols = OW;
+        pl->kh0[0] = 0; pl->kw0[0] = 0; pl->khs = 1; pl->kws = 1;
+        np = 1;
+    } else {
+        if (d.sh * d.sw > kB16MaxPhase) return bad("conv2d_b16: more than 4 output phases");
+        a.sih = 1; a.siw = 1; a.soh = d.sh; a.sow = d.sw;
+        // stride 1 on an axis: one phase holding every tap, walked backwards with the dilation as step
+        a.tdh = d.sh == 1 ? -d.dh : -1; a.tdw = d.sw == 1 ? -d.dw : -1;
+        pl->khs = d.sh; pl->kws = d.sw;
+        for (int ah = 0; ah < d.sh; ++ah)
+            for (int aw = 0; aw < d.sw; ++aw) {
+                B16Phase& p = a.ph[np];
+                const int kh0 = (ah + d.ph) % d.sh, kw0 = (aw + d.pw) % d.sw;
+                p.nth = kh0 < d.kh ? (d.kh - kh0 + d.sh - 1) / d.sh : 0;
+                p.ntw = kw0 < d.kw ? (d.kw - kw0 + d.sw - 1) / d.sw : 0;
+                if (p.nth < 1 || p.ntw < 1) return bad("conv2d_b16: an output phase without taps (kernel smaller than stride)");
+                // oh = ih*s - p + k*d  ->  ih = (oh + p - k*d) / s ; with oh = i*s + a and k = k0 + t*s (d = 1 when s > 1)
+                p.offh = d.sh == 1 ? d.ph : (ah + d.ph - kh0) / d.sh;
+                p.offw = d.sw == 1 ? d.pw : (aw + d.pw - kw0) / d.sw;
+                p.poh = ah; p.pow_ = aw;
+                p.rows = OH > ah ? (OH - ah + d.sh - 1) / d.sh : 0;
+                p.cols = OW > aw ? (OW - aw + d.sw - 1) / d.sw : 0;
+                pl->kh0[np] = kh0; pl->kw0[np] = kw0;
+                ++np;
+            }
+    }
+    a.nphase = np;
+    // tile width: two column tiles unless the input image of a group would pass 32 KB
+    int max_nth = 0, max_ntw = 0;
+    for (int q = 0; q < np; ++q) {
+        max_nth = std::max(max_nth, a.ph[q].nth); max_ntw = std::max(max_ntw, a.ph[q].ntw);
+        if (a.ph[q].nth == 1) single_row_group = true;
+    }
+    a.din = single_row_group ? 2 : 1;
+    auto in_bytes = [&](int nt) {
+        const int rows_in = (kB16Waves - 1) * a.sih + (max_nth - 1) * std::abs(a.tdh) + 1;
+        const int cols_in = (32 * nt - 1) * a.siw + (max_ntw - 1) * std::abs(a.tdw) + 1;
+        return (size_t)(((2 * rows_in * cols_in + 63) / 64) * 1024);
+    };
+    pl->NT = (pl->MT <= 3 && in_bytes(2) <= 32 * 1024) ? 2 : 1;
+    a.in_buf_bytes = (int)in_bytes(pl->NT);
+    if (a.in_buf_bytes > kB16MaxQ * kB16Waves * 1024) return bad("conv2d_b16: input image of one channel group exceeds 64 KB");
+    a.w_buf_bytes = max_ntw * hl * pl->MT * 1024;
+    pl->lds_bytes = (size_t)(a.din + 1) * a.in_buf_bytes + (size_t)kB16WRing * a.w_buf_bytes + 5 * pl->MT * 32 * 4;
+    if (pl->lds_bytes > 160 * 1024) return bad("conv2d_b16: LDS images exceed 160 KB");
+    // weight image and grid
+    const int G = a.G0 + a.G1;
+    size_t woff = 0;
+    unsigned long long wg = 0;
+    for (int q = 0; q < np; ++q) {
+        B16Phase& p = a.ph[q];
+        p.w_off = (unsigned)woff;
+        p.w_bytes = (unsigned)((size_t)G * p.nth * p.ntw * hl * pl->MT * 1024);
+        woff += p.w_bytes;
+        const unsigned long long njt = (p.cols + 32 * pl->NT - 1) / (32 * pl->NT), nit = (p.rows + kB16Waves - 1) / kB16Waves;
+        wg += njt * nit * (unsigned long long)d.N;
+        p.wg_end = (unsigned)wg;
+    }
+    if (wg >= 0x7fffffffull) return bad("conv2d_b16: too many workgroups");
+    if (woff >= ((size_t)1 << 31)) return bad("conv2d_b16: weight image larger than 2 GB");
+    pl->grid = (unsigned)wg;
+    pl->packed_bytes = woff;
+    return true;
+}
+
+template <int MT, int NT>
+static hipError_t launch_b16(const B16Plan& pl, hipStream_t stream) {
+    static bool raised = false;
+    if (!raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<MT, NT>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((conv_b16_kernel<MT, NT>), dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
+    return hipGetLastError();
+}
+
+}  // namespace unetmi
+
+using namespace unetmi;
+
+extern "C" {
+
+size_t unetmi_conv2d_b16_packed_weight_bytes(const UnetmiConvDesc* d) {
+    if (!d) { api_fail(UNETMI_E_BAD_ARG, "null descriptor"); return 0; }
+    B16Plan pl;
+    std::string err;
+    if (!make_b16_plan(*d, &pl, &err)) { api_fail(UNETMI_E_BAD_DESC, err); return 0; }
+    return pl.packed_bytes;
+}
+
+int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void* packed) {
+    if (!d || !w || !packed) return api_fail(UNETMI_E_BAD_ARG, "null argument to conv2d_b16_pack_weights");
+    B16Plan pl;
+    std::string err;
+    if (!make_b16_plan(*d, &pl, &err)) return api_fail(UNETMI_E_BAD_DESC, err);
+    const B16Args& a = pl.args;
+    std::memset(packed, 0, pl.packed_bytes);
+    const int C = d->C0 + d->C1, K = d->K, KH = d->kh, KW = d->kw, G = a.G0 + a.G1, MT = pl.MT;
+    for (int q = 0; q < a.nphase; ++q) {
+        const B16Phase& p = a.ph[q];
+        unsigned short* img = reinterpret_cast<unsigned short*>(static_cast<char*>(packed) + p.w_off);
+        for (int g = 0; g < G; ++g)
+            for (int th = 0; th < p.nth; ++th)
+                for (int tw = 0; tw < p.ntw; ++tw) {
+                    const int ky = pl.kh0[q] + th * pl.khs, kx = pl.kw0[q] + tw * pl.kws;
+                    for (int h = 0; h < a.hl; ++h)
+                        for (int mt = 0; mt < MT; ++mt)
+                            for (int hf = 0; hf < 2; ++hf)
+                                for (int row = 0; row < 32; ++row)
+                                    for (int k = 0; k < 8; ++k) {
+                                        const size_t dst = ((((((size_t)(g * p.nth + th) * p.ntw + tw) * a.hl + h) * MT + mt) * 2 + hf) * 32 + row) * 8 + k;
+                                        const int cl = (g < a.G0 ? g : g - a.G0) * 16 + hf * 8 + k;
+                                        const int ci = g < a.G0 ? (cl < d->C0 ? cl : -1) : (cl < d->C1 ? d->C0 + cl : -1);
+                                        const int co = mt * 32 + row;
+                                        if (ci < 0 || co >= K) continue;
+                                        const size_t src = d->transposed ? (((size_t)ci * K + co) * KH + ky) * KW + kx
+                                                                         : (((size_t)co * C + ci) * KH + ky) * KW + kx;
+                                        const unsigned short hi = host_bf16(w[src]);
+                                        img[dst] = h == 0 ? hi : host_bf16(w[src] - host_bf16_to_f32(hi));
+                                    }
+                }
+    }
+    return UNETMI_OK;
+}
+
+int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
+                          const float* bias, const float* scale, const float* shift, const float* act_param,
+                          const float* gate, void* out, void* stream) {
+    if (!d) return api_fail(UNETMI_E_BAD_ARG, "null descriptor");
+    B16Plan pl;
+    std::string err;
+    if (!make_b16_plan(*d, &pl, &err)) return api_fail(UNETMI_E_BAD_DESC, err);
+    if (d->N == 0) return UNETMI_OK;
+    if (!in0 || !wpacked || !bias || !scale || !shift || !out) return api_fail(UNETMI_E_BAD_ARG, "null tensor pointer");
+    if (d->in_mode == UNETMI_IN_CONCAT && !in1) return api_fail(UNETMI_E_BAD_ARG, "concat needs in1");
+    if (d->act == UNETMI_ACT_LEAKY && !act_param) return api_fail(UNETMI_E_BAD_ARG, "leaky/prelu needs act_param");
+    if ((d->has_gate != 0) != (gate != nullptr)) return api_fail(UNETMI_E_BAD_ARG, "gate pointer vs has_gate");
+    B16Args& a = pl.args;
+    a.in0 = static_cast<const char*>(in0); a.in1 = static_cast<const char*>(in1); a.w = static_cast<const char*>(wpacked);
+    a.bias = bias; a.scale = scale; a.shift = shift; a.act_param = act_param; a.gate = gate; a.out = out;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipErrorInvalidConfiguration;
+#define UNETMI_B16(MT_, NT_) if (pl.MT == MT_ && pl.NT == NT_) e = launch_b16<MT_, NT_>(pl, st);
+    UNETMI_B16(1, 1) UNETMI_B16(1, 2) UNETMI_B16(2, 1) UNETMI_B16(2, 2) UNETMI_B16(3, 1) UNETMI_B16(3, 2) UNETMI_B16(4, 1)
+#undef UNETMI_B16
+    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("conv2d_b16 launch: ") + hipGetErrorString(e));
+    return UNETMI_OK;
+}
+
+int unetmi_blocked_from_nchw(int N, int C, int HW, const void* src, int src_dtype, void* dst, void* stream) {
+    if (N < 0 || C < 1 || HW < 1) return api_fail(UNETMI_E_BAD_DESC, "blocked_from_nchw: bad sizes");
+    if (N == 0) return UNETMI_OK;
+    if (!src || !dst) return api_fail(UNETMI_E_BAD_ARG, "blocked_from_nchw: null pointer");
+    const int CB = 2 * ((C + 15) / 16);
+    if (N > 65535 || CB > 65535) return api_fail(UNETMI_E_UNSUPPORTED, "blocked_from_nchw: N or C too large");
+    const dim3 grid((HW + 255) / 256, CB, N);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (src_dtype == UNETMI_DTYPE_BF16) hipLaunchKernelGGL((to_blocked_kernel<true>), grid, dim3(256), 0, st, src, static_cast<char*>(dst), C, CB, HW);
+    else if (src_dtype == UNETMI_DTYPE_F32) hipLaunchKernelGGL((to_blocked_kernel<false>), grid, dim3(256), 0, st, src, static_cast<char*>(dst), C, CB, HW);
+    else return api_fail(UNETMI_E_BAD_DESC, "blocked_from_nchw: unknown dtype");
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("blocked_from_nchw launch: ") + hipGetErrorString(e));
+}
+
+int unetmi_nchw_from_blocked(int N, int C, int HW, const void* src, void* dst, int dst_dtype, void* stream) {
+    if (N < 0 || C < 1 || HW < 1) return api_fail(UNETMI_E_BAD_DESC, "nchw_from_blocked: bad sizes");
+    if (N == 0) return UNETMI_OK;
+    if (!src || !dst) return api_fail(UNETMI_E_BAD_ARG, "nchw_from_blocked: null pointer");
+    const int CB = 2 * ((C + 15) / 16);
+    if (N > 65535 || CB > 65535) return api_fail(UNETMI_E_UNSUPPORTED, "nchw_from_blocked: N or C too large");
+    const dim3 grid((HW + 255) / 256, CB, N);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dst_dtype == UNETMI_DTYPE_BF16) hipLaunchKernelGGL((from_blocked_kernel<true>), grid, dim3(256), 0, st, static_cast<const char*>(src), dst, C, CB, HW);
+    else if (dst_dtype == UNETMI_DTYPE_F32) hipLaunchKernelGGL((from_blocked_kernel<false>), grid, dim3(256), 0, st, static_cast<const char*>(src), dst, C, CB, HW);
+    else return api_fail(UNETMI_E_BAD_DESC, "nchw_from_blocked: unknown dtype");
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("nchw_from_blocked launch: ") + hipGetErrorString(e));
+}
+
+}  // extern "C"
