@@ -1,0 +1,59 @@
+"""Times single layers of the bf16-operand blocked convolution (DSUNet shapes, batch 32).
+
+    python tools/b16_probe.py [layer ...]
+
+Used with build-time experiment variants of the library (make CXXFLAGS+=-DB16_ABLATE=n) to see where a
+layer's time goes: 1 = no MFMA loop, 2 = no operand DMA after the prologue, 4 = no epilogue.
+"""
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+LAYERS = {
+    # name: (C0, C1, K, kernel, stride, padding, output_padding, transposed, H, W)
+    "enc1": (8, 0, 45, (7, 1), (1, 1), (3, 0), (0, 0), False, 257, 512),
+    "enc2": (45, 0, 45, (1, 7), (1, 1), (0, 3), (0, 0), False, 257, 512),
+    "enc3": (45, 0, 90, (7, 5), (2, 2), (3, 2), (0, 0), False, 257, 512),
+    "enc4": (90, 0, 90, (7, 5), (2, 1), (3, 2), (0, 0), False, 129, 256),
+    "dec6": (90, 90, 90, (7, 5), (2, 1), (3, 2), (0, 0), True, 65, 256),
+    "dec7": (90, 90, 90, (7, 5), (2, 2), (3, 2), (0, 1), True, 129, 256),
+    "dec8": (90, 45, 90, (1, 7), (1, 1), (0, 3), (0, 0), True, 257, 512),
+    "dec9": (90, 8, 90, (7, 1), (1, 1), (3, 0), (0, 0), True, 257, 512),
+    "head": (90, 0, 2, (1, 1), (1, 1), (0, 0), (0, 0), False, 257, 512),
+}
+
+
+def main():
+    from unet_amd.blocked import BlockedConv, BlockedTensor
+    names = sys.argv[1:] or list(LAYERS)
+    dev = torch.device("cuda", 0)
+    N = 32
+    for name in names:
+        C0, C1, K, k, s, p, op, tr, H, W = LAYERS[name]
+        conv = (nn.ConvTranspose2d(C0 + C1, K, k, stride=s, padding=p, output_padding=op) if tr
+                else nn.Conv2d(C0 + C1, K, k, stride=s, padding=p))
+        bn = nn.BatchNorm2d(K).eval()
+        layer = BlockedConv(conv, bn, nn.LeakyReLU(0.01), nchw_out=(name == "head"))
+        x0 = BlockedTensor(torch.randn(N, 2 * ((C0 + 15) // 16), H, W, 8, device=dev).to(torch.bfloat16), C0)
+        x1 = BlockedTensor(torch.randn(N, 2 * ((C1 + 15) // 16), H, W, 8, device=dev).to(torch.bfloat16), C1) if C1 else None
+        for _ in range(3):
+            y = layer(x0, x1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            y = layer(x0, x1)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        oh, ow = (y.shape[2], y.shape[3])
+        taps = k[0] * k[1] / ((s[0] * s[1]) if tr else 1)
+        flop = 2.0 * (C0 + C1) * K * taps * oh * ow * N
+        print("{:5s} {:8.1f} us  {:7.1f} TFLOP/s".format(name, dt * 1e6, flop / dt / 1e12), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@ count and its forward raises (DSUNet.py:541-545, :588).
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .fused import FusedConv, activation_code, require_device_tensor
 from .ops import glu
 
@@ -335,8 +336,10 @@ class DSUNet(nn.Module):
             ok = isinstance(self.BTN, nn.Identity) and activation_code(self.mask.squash) is not None
             for m in list(self.encoders) + list(self.decoders):
                 conv = getattr(m, "conv", None) if isinstance(m, Encoder) else getattr(m, "transconv", None)
+                code = activation_code(m.relu)        # the wide layers' epilogue has LeakyReLU / PReLU / ReLU only
                 ok = ok and isinstance(m, (Encoder, Decoder)) and isinstance(m.bn, nn.BatchNorm2d) and \
-                    activation_code(m.relu) is not None and conv.out_channels <= 128 and \
+                    code is not None and code[0] in (_lib.ACT_NONE, _lib.ACT_LEAKY, _lib.ACT_RELU) and \
+                    conv.out_channels <= 128 and \
                     getattr(conv, "padding_mode", "zeros") == "zeros"
             built = False
             if ok:

@@ -39,6 +39,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float b16_f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* b16_lds_ptr;
 
+#ifndef B16_ABLATE
+#define B16_ABLATE 0      // build-time experiment switches (tools/b16_probe.py); 0 in the shipped library
+#endif
 constexpr int kB16MaxPhase = 4;
 constexpr int kB16Waves = 8;          // waves (= output rows) per workgroup
 constexpr int kB16MaxQ = 8;           // input DMA instructions per wave and group (64 KB image)
@@ -67,16 +70,19 @@ struct B16Args {
     B16Phase ph[kB16MaxPhase];
 };
 
-__device__ __forceinline__ float b16_act(float v, int act, float slope) {
+// Activations.  LeakyReLU / PReLU / ReLU / none are one select with a per-channel slope (1 for none, 0 for
+// ReLU) and are what the wide layers use.  The transcendental ones go through a run-time switch, which
+// is only instantiated for layers of at most 32 output channels (the mask heads): inlined once per
+// accumulator register of a wide tile that switch made the epilogue ~80,000 instructions of mostly
+// skipped code, and the instruction-cache misses of the skips cost more than the whole matrix loop.
+__device__ __forceinline__ float b16_act_general(float v, int act, float slope) {
     switch (act) {
-        case UNETMI_ACT_LEAKY:    return v >= 0.f ? v : v * slope;
-        case UNETMI_ACT_RELU:     return fmaxf(v, 0.f);
         case UNETMI_ACT_SILU:     return v / (1.f + expf(-v));
         case UNETMI_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
         case UNETMI_ACT_SIGMOID:  return 1.f / (1.f + expf(-v));
         case UNETMI_ACT_TANH:     return tanhf(v);
         case UNETMI_ACT_GELU:     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        default:                  return v;
+        default:                  return v >= 0.f ? v : v * slope;
     }
 }
 
@@ -104,7 +110,64 @@ __device__ __forceinline__ void b16_wait_vm(int n) {
     }
 }
 
-template <int MT, int NT>
+// Bias, folded BatchNorm, activation and gate on the fp32 accumulators, then either 8-byte stores of
+// four bfloat16 channels (lanes l and l+32 complete a pixel's 16-byte record, a wave writes 512
+// contiguous bytes per instruction) or plain fp32 NCHW stores for the heads.
+template <int MT, int NT, bool GEN>
+__device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], const B16Args& p, const float* s_par,
+                                             int n, int oh, int j0, int pcol, int pow_, int half, int j) {
+    const int CBo = 2 * ((p.K + 15) >> 4);
+    const size_t OHW = (size_t)p.OH * p.OW;
+    size_t pix[NT];
+    bool ok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int jc = j0 + nt * 32 + j;
+        ok[nt] = jc < pcol;
+        pix[nt] = (size_t)oh * p.OW + (size_t)(jc * p.sow + pow_);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int blk = mt * 4 + q;
+            const int m0 = blk * 8 + half * 4;
+            float bi[4], sc[4], sf[4], sl[4], gt[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bi[r] = s_par[m0 + r]; sc[r] = s_par[MT * 32 + m0 + r]; sf[r] = s_par[2 * MT * 32 + m0 + r];
+                sl[r] = s_par[3 * MT * 32 + m0 + r]; gt[r] = s_par[4 * MT * 32 + m0 + r];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[mt][nt][q * 4 + r] + bi[r];
+                    if (p.act_first) x = (GEN ? b16_act_general(x, p.act, sl[r]) : (x >= 0.f ? x : x * sl[r])) * sc[r] + sf[r];
+                    else {
+                        x = x * sc[r] + sf[r];
+                        x = GEN ? b16_act_general(x, p.act, sl[r]) : (x >= 0.f ? x : x * sl[r]);
+                    }
+                    v[r] = x * gt[r];
+                }
+                if (p.out_nchw_f32) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[nt] && m0 + r < p.K)
+                            static_cast<float*>(p.out)[((size_t)n * p.K + m0 + r) * OHW + pix[nt]] = v[r];
+                } else if (ok[nt] && blk < CBo) {
+                    uint2 w2;
+                    w2.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                    w2.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                    char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + pix[nt]) * 16 + half * 8;
+                    *reinterpret_cast<uint2*>(o) = w2;
+                }
+            }
+        }
+}
+
+template <int MT, int NT, bool GEN>
 __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -202,7 +265,8 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
         float par[5] = {0.f, 0.f, 0.f, 0.f, 0.f};       // channels past K produce exact zeros
         if (tid < p.K) {
             par[0] = p.bias[tid]; par[1] = p.scale[tid]; par[2] = p.shift[tid];
-            if (p.act_param) par[3] = p.act_param[p.act_pc ? tid : 0];
+            par[3] = p.act == UNETMI_ACT_NONE ? 1.f : 0.f;                   // slope of the select: none = 1, ReLU = 0
+            if (p.act == UNETMI_ACT_LEAKY) par[3] = p.act_param[p.act_pc ? tid : 0];
             par[4] = p.gate ? p.gate[(size_t)n * p.K + tid] : 1.f;
         }
 #pragma unroll
@@ -230,14 +294,14 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
     for (int g = 0; g < G; ++g) {
         const char* in_img = s_in + (g % nin_buf) * p.in_buf_bytes;
         for (int th = 0; th < nth; ++th, ++s) {
-            int issued = issue_weights(s + 2);
-            if (th == 0) issued += issue_input(g + p.din);
+            int issued = (B16_ABLATE & 2) ? 0 : issue_weights(s + 2);
+            if (th == 0 && !(B16_ABLATE & 2)) issued += issue_input(g + p.din);
 
             const int rowl = wave * p.sih + th * p.tdh - negh;
             const char* brow = in_img + (half * plane + rowl * cols_in) * 16;
             const char* wimg = s_w + (s % kB16WRing) * p.w_buf_bytes + a_lane;
 #pragma unroll 1
-            for (int tw = 0; tw < ntw; ++tw) {
+            for (int tw = 0; tw < ((B16_ABLATE & 1) ? 0 : ntw); ++tw) {
                 bf16x8 B[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -264,43 +328,7 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
     const int i = i0 + wave;
     if (i >= prow) return;                              // wave-uniform
     const int oh = i * p.soh + p.ph[a].poh;
-    const int CBo = 2 * ((p.K + 15) >> 4);
-    const size_t OHW = (size_t)p.OH * p.OW;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int jc = j0 + nt * 32 + j;
-        if (jc >= pcol) continue;
-        const int ow = jc * p.sow + p.ph[a].pow_;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mt * 32 + q * 8 + half * 4 + r;
-                    float x = acc[mt][nt][q * 4 + r] + s_par[m];
-                    const float sc = s_par[MT * 32 + m], sf = s_par[2 * MT * 32 + m], sl = s_par[3 * MT * 32 + m];
-                    if (p.act_first) x = b16_act(x, p.act, sl) * sc + sf;
-                    else             x = b16_act(x * sc + sf, p.act, sl);
-                    v[r] = x * s_par[4 * MT * 32 + m];
-                }
-                const int blk = mt * 4 + q;
-                if (p.out_nchw_f32) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = blk * 8 + half * 4 + r;
-                        if (m < p.K) static_cast<float*>(p.out)[((size_t)n * p.K + m) * OHW + (size_t)oh * p.OW + ow] = v[r];
-                    }
-                } else if (blk < CBo) {
-                    uint2 w2;
-                    w2.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                    w2.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-                    char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + (size_t)oh * p.OW + ow) * 16 + half * 8;
-                    *reinterpret_cast<uint2*>(o) = w2;
-                }
-            }
-    }
+    b16_epilogue<MT, NT, GEN>(acc, p, s_par, n, oh, j0, pcol, p.ph[a].pow_, half, j);
 }
 
 // ---- layout conversion ------------------------------------------------------------------------
@@ -460,16 +488,16 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     return true;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool GEN>
 static hipError_t launch_b16(const B16Plan& pl, hipStream_t stream) {
     static bool raised = false;
     if (!raised) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<MT, NT>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<MT, NT, GEN>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((conv_b16_kernel<MT, NT>), dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
+    hipLaunchKernelGGL((conv_b16_kernel<MT, NT, GEN>), dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
     return hipGetLastError();
 }
 
@@ -539,8 +567,13 @@ int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* 
     a.bias = bias; a.scale = scale; a.shift = shift; a.act_param = act_param; a.gate = gate; a.out = out;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipErrorInvalidConfiguration;
-#define UNETMI_B16(MT_, NT_) if (pl.MT == MT_ && pl.NT == NT_) e = launch_b16<MT_, NT_>(pl, st);
-    UNETMI_B16(1, 1) UNETMI_B16(1, 2) UNETMI_B16(2, 1) UNETMI_B16(2, 2) UNETMI_B16(3, 1) UNETMI_B16(3, 2) UNETMI_B16(4, 1)
+    const bool gen = d->act != UNETMI_ACT_NONE && d->act != UNETMI_ACT_LEAKY && d->act != UNETMI_ACT_RELU;
+    if (gen && pl.MT > 1)
+        return api_fail(UNETMI_E_UNSUPPORTED, "conv2d_b16: SiLU / Softplus / Sigmoid / Tanh / GELU epilogues are built for K <= 32 only");
+#define UNETMI_B16(MT_, NT_, GEN_) if (pl.MT == MT_ && pl.NT == NT_ && gen == GEN_) e = launch_b16<MT_, NT_, GEN_>(pl, st);
+    UNETMI_B16(1, 1, false) UNETMI_B16(1, 2, false) UNETMI_B16(2, 1, false) UNETMI_B16(2, 2, false)
+    UNETMI_B16(3, 1, false) UNETMI_B16(3, 2, false) UNETMI_B16(4, 1, false)
+    UNETMI_B16(1, 1, true) UNETMI_B16(1, 2, true)
 #undef UNETMI_B16
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("conv2d_b16 launch: ") + hipGetErrorString(e));
     return UNETMI_OK;
