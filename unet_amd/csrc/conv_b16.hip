@@ -24,7 +24,9 @@
 // which reproduces fp32-weight arithmetic (bf16 x bf16 products are exact in fp32).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -38,6 +40,12 @@ int api_fail(int code, const std::string& msg);
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float b16_f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* b16_lds_ptr;
+typedef __bf16 b16_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float b16_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned b16_pack2(float lo, float hi) {        // v_cvt_pk_bf16_f32: nearest-even
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(b16_f32x2{lo, hi}, b16_bf16x2));
+}
 
 #ifndef B16_ABLATE
 #define B16_ABLATE 0      // build-time experiment switches (tools/b16_probe.py); 0 in the shipped library
@@ -45,7 +53,6 @@ typedef __attribute__((address_space(3))) void* b16_lds_ptr;
 constexpr int kB16MaxPhase = 4;
 constexpr int kB16Waves = 8;          // waves (= output rows) per workgroup
 constexpr int kB16MaxQ = 8;           // input DMA instructions per wave and group (64 KB image)
-constexpr int kB16WRing = 3;
 
 struct B16Phase {
     int nth, ntw;            // taps of this phase
@@ -65,6 +72,7 @@ struct B16Args {
     int G0, G1;              // 16-channel groups of the two sources
     int sih, siw, tdh, tdw, soh, sow;
     int nphase, hl, din;     // weight halves (1 | 2); input prefetch distance in groups (1 | 2)
+    int wring, allrows;      // weight ring depth (2 | 3); 1: one step holds every tap row of a group
     int in_buf_bytes, w_buf_bytes;
     int act, act_first, act_pc, out_nchw_f32;
     B16Phase ph[kB16MaxPhase];
@@ -158,8 +166,8 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
                             static_cast<float*>(p.out)[((size_t)n * p.K + m0 + r) * OHW + pix[nt]] = v[r];
                 } else if (ok[nt] && blk < CBo) {
                     uint2 w2;
-                    w2.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                    w2.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                    w2.x = b16_pack2(v[0], v[1]);
+                    w2.y = b16_pack2(v[2], v[3]);
                     char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + pix[nt]) * 16 + half * 8;
                     *reinterpret_cast<uint2*>(o) = w2;
                 }
@@ -167,8 +175,11 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
         }
 }
 
-template <int MT, int NT, bool GEN>
-__global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
+// OCC2: built for two workgroups per CU (128 registers, LDS images <= 80 KB, input image <= 32 KB), so one
+// workgroup's prologue and epilogue run under the other's matrix loop.
+template <int MT, int NT, bool GEN, bool OCC2>
+__device__ __forceinline__ void conv_b16_body(const B16Args& p) {
+    constexpr int MAXQ = OCC2 ? kB16MaxQ / 2 : kB16MaxQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
     const int nin_buf = p.din + 1;
     char* const s_in = smem;
     char* const s_w = smem + nin_buf * p.in_buf_bytes;
-    float* const s_par = reinterpret_cast<float*>(s_w + kB16WRing * p.w_buf_bytes);   // [5][MT*32]
+    float* const s_par = reinterpret_cast<float*>(s_w + p.wring * p.w_buf_bytes);     // [5][MT*32]
 
     // ---- this workgroup's phase and tile ----------------------------------------------
     unsigned bid = blockIdx.x;
@@ -207,9 +218,9 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
     const int HW = p.H * p.W;
 
     // ---- per-lane byte offsets of this wave's input DMA instructions (same for every group) ----
-    int voff[kB16MaxQ];
+    int voff[MAXQ];
 #pragma unroll
-    for (int k = 0; k < kB16MaxQ; ++k) {
+    for (int k = 0; k < MAXQ; ++k) {
         const int e = (wave + kB16Waves * k) * 64 + lane;
         int off = (int)0x80000000;
         if (e < slots) {
@@ -223,9 +234,11 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
     }
 
     const int G = p.G0 + p.G1;
-    const int step_bytes = ntw * p.hl * MT * 1024;
-    const int n_w_instr = ntw * p.hl * MT;
-    const int S = G * nth;
+    const int R = p.allrows ? nth : 1;               // tap rows per step
+    const int nchunk = nth / R;
+    const int step_bytes = R * ntw * p.hl * MT * 1024;
+    const int n_w_instr = R * ntw * p.hl * MT;
+    const int S = G * nchunk;
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + p.ph[a].w_off), 0, (int)p.ph[a].w_bytes, 0x00020000);
 
     auto issue_input = [&](int g) -> int {            // group g -> its ring slot; returns instructions issued
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
         char* dst = s_in + (g % nin_buf) * p.in_buf_bytes;
         int cnt = 0;
 #pragma unroll
-        for (int k = 0; k < kB16MaxQ; ++k) {
+        for (int k = 0; k < MAXQ; ++k) {
             const int q = wave + kB16Waves * k;
             if (q < n_in_instr) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (b16_lds_ptr)(dst + q * 1024), 16, voff[k], soff, 0, 0);
@@ -248,9 +261,9 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
         }
         return cnt;
     };
-    auto issue_weights = [&](int s) -> int {          // step s -> ring slot s % 3
+    auto issue_weights = [&](int s) -> int {          // step s -> ring slot s % wring
         if (s >= S) return 0;
-        char* dst = s_w + (s % kB16WRing) * p.w_buf_bytes;
+        char* dst = s_w + (s % p.wring) * p.w_buf_bytes;
         const int soff0 = s * step_bytes;
         int cnt = 0;
         for (int q = wave; q < n_w_instr; q += kB16Waves) {
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
     }
     for (int g = 0; g < p.din; ++g) issue_input(g);
     issue_weights(0);
-    issue_weights(1);
+    if (p.wring == 3) issue_weights(1);
     __syncthreads();                                   // full drain once
 
     b16_f32x16 acc[MT][NT];
@@ -293,32 +306,35 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
     int s = 0;
     for (int g = 0; g < G; ++g) {
         const char* in_img = s_in + (g % nin_buf) * p.in_buf_bytes;
-        for (int th = 0; th < nth; ++th, ++s) {
-            int issued = (B16_ABLATE & 2) ? 0 : issue_weights(s + 2);
-            if (th == 0 && !(B16_ABLATE & 2)) issued += issue_input(g + p.din);
+        for (int tc = 0; tc < nchunk; ++tc, ++s) {
+            int issued = (B16_ABLATE & 2) ? 0 : issue_weights(s + p.wring - 1);
+            if (tc == 0 && !(B16_ABLATE & 2)) issued += issue_input(g + p.din);
 
-            const int rowl = wave * p.sih + th * p.tdh - negh;
-            const char* brow = in_img + (half * plane + rowl * cols_in) * 16;
-            const char* wimg = s_w + (s % kB16WRing) * p.w_buf_bytes + a_lane;
+            const char* wimg = s_w + (s % p.wring) * p.w_buf_bytes + a_lane;
+            for (int tr = 0; tr < R; ++tr) {
+                const int th = tc * R + tr;
+                const int rowl = wave * p.sih + th * p.tdh - negh;
+                const char* brow = in_img + (half * plane + rowl * cols_in) * 16;
 #pragma unroll 1
-            for (int tw = 0; tw < ((B16_ABLATE & 1) ? 0 : ntw); ++tw) {
-                bf16x8 B[NT];
+                for (int tw = 0; tw < ((B16_ABLATE & 1) ? 0 : ntw); ++tw) {
+                    bf16x8 B[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    B[nt] = *reinterpret_cast<const bf16x8*>(brow + colb[nt] + tw * p.tdw * 16);
-                for (int h = 0; h < p.hl; ++h) {
-                    const char* wt = wimg + (tw * p.hl + h) * MT * 1024;
+                    for (int nt = 0; nt < NT; ++nt)
+                        B[nt] = *reinterpret_cast<const bf16x8*>(brow + colb[nt] + tw * p.tdw * 16);
+                    for (int h = 0; h < p.hl; ++h) {
+                        const char* wt = wimg + ((tr * ntw + tw) * p.hl + h) * MT * 1024;
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[nt], acc[mt][nt], 0, 0, 0);
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[nt], acc[mt][nt], 0, 0, 0);
+                        }
                     }
                 }
             }
             // everything issued before this step has to have landed; this step's own loads may fly on
-            b16_wait_vm(__builtin_amdgcn_readfirstlane(issued));
+            b16_wait_vm(p.wring == 3 ? __builtin_amdgcn_readfirstlane(issued) : 0);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
@@ -330,6 +346,12 @@ __global__ __launch_bounds__(512) void conv_b16_kernel(const B16Args p) {
     const int oh = i * p.soh + p.ph[a].poh;
     b16_epilogue<MT, NT, GEN>(acc, p, s_par, n, oh, j0, pcol, p.ph[a].pow_, half, j);
 }
+
+template <int MT, int NT, bool GEN>
+__global__ __launch_bounds__(512, 2) void conv_b16_kernel(const B16Args p) { conv_b16_body<MT, NT, GEN, false>(p); }
+
+template <int MT, int NT>
+__global__ __launch_bounds__(512, 4) void conv_b16_kernel_occ2(const B16Args p) { conv_b16_body<MT, NT, false, true>(p); }
 
 // ---- layout conversion ------------------------------------------------------------------------
 // NCHW (fp32 or bfloat16) -> blocked; a thread owns one pixel of one 8-channel block.
@@ -370,6 +392,7 @@ __global__ __launch_bounds__(256) void from_blocked_kernel(const char* src, void
 struct B16Plan {
     B16Args args;
     int MT, NT;
+    bool occ2;
     unsigned grid;
     size_t lds_bytes, packed_bytes;
     int kh0[kB16MaxPhase], kw0[kB16MaxPhase], khs, kws;      // kernel index of tap t: k0 + t * ks
@@ -419,7 +442,6 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     if (pl->MT > 4) return bad("conv2d_b16: more than 128 output channels");
     if ((size_t)2 * std::max(a.G0, a.G1) * d.H * d.W * 16 >= (size_t)1 << 31) return bad("conv2d_b16: sample larger than 2 GB");
     int np = 0;
-    bool single_row_group = false;
     if (!d.transposed) {
         a.sih = d.sh; a.siw = d.sw; a.tdh = d.dh; a.tdw = d.dw; a.soh = 1; a.sow = 1;
         B16Phase& p = a.ph[0];
@@ -450,24 +472,50 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
             }
     }
     a.nphase = np;
-    // tile width: two column tiles unless the input image of a group would pass 32 KB
+    // Tile shape and pipeline depth.  Preference: two workgroups per CU (weight ring of 2, LDS <= 80 KB each,
+    // one workgroup's prologue / epilogue hidden under the other's matrix loop) with two column tiles, then with
+    // one; else one workgroup per CU with a ring of 3.  A step takes every tap row of a channel group when
+    // those weights are at most 24 KB (kernels one column wide would otherwise hit a barrier every few MFMAs).
     int max_nth = 0, max_ntw = 0;
+    bool one_row_phase = false;
     for (int q = 0; q < np; ++q) {
         max_nth = std::max(max_nth, a.ph[q].nth); max_ntw = std::max(max_ntw, a.ph[q].ntw);
-        if (a.ph[q].nth == 1) single_row_group = true;
+        if (a.ph[q].nth == 1) one_row_phase = true;
     }
-    a.din = single_row_group ? 2 : 1;
+    a.allrows = (max_nth > 1 && max_nth * max_ntw * hl * pl->MT <= 24) ? 1 : 0;
+    const bool single_step_group = a.allrows || one_row_phase;
     auto in_bytes = [&](int nt) {
         const int rows_in = (kB16Waves - 1) * a.sih + (max_nth - 1) * std::abs(a.tdh) + 1;
         const int cols_in = (32 * nt - 1) * a.siw + (max_ntw - 1) * std::abs(a.tdw) + 1;
         return (size_t)(((2 * rows_in * cols_in + 63) / 64) * 1024);
     };
-    pl->NT = (pl->MT <= 3 && in_bytes(2) <= 32 * 1024) ? 2 : 1;
-    a.in_buf_bytes = (int)in_bytes(pl->NT);
-    if (a.in_buf_bytes > kB16MaxQ * kB16Waves * 1024) return bad("conv2d_b16: input image of one channel group exceeds 64 KB");
-    a.w_buf_bytes = max_ntw * hl * pl->MT * 1024;
-    pl->lds_bytes = (size_t)(a.din + 1) * a.in_buf_bytes + (size_t)kB16WRing * a.w_buf_bytes + 5 * pl->MT * 32 * 4;
-    if (pl->lds_bytes > 160 * 1024) return bad("conv2d_b16: LDS images exceed 160 KB");
+    a.w_buf_bytes = (a.allrows ? max_nth : 1) * max_ntw * hl * pl->MT * 1024;
+    const size_t par_bytes = 5 * pl->MT * 32 * 4;
+    const bool general_act = d.act != UNETMI_ACT_NONE && d.act != UNETMI_ACT_LEAKY && d.act != UNETMI_ACT_RELU;
+    int force_nt = 0, force_occ = -1;
+    if (const char* e = std::getenv("UNETMI_B16_MODE")) {     // "nt,occ2" for experiments, e.g. "2,0"
+        force_nt = e[0] - '0';
+        if (e[1] == ',' && e[2]) force_occ = e[2] - '0';
+    }
+    bool found = false;
+    for (int c = 0; c < 4 && !found; ++c) {
+        const int nt = (c & 1) ? 1 : 2;
+        const bool occ2 = c < 2;
+        if (nt == 2 && pl->MT > 3) continue;
+        if (occ2 && general_act) continue;
+        if (force_nt && nt != force_nt) continue;
+        if (force_occ >= 0 && (int)occ2 != force_occ) continue;
+        const size_t ib = in_bytes(nt);
+        const int din = occ2 ? 1 : (single_step_group ? 2 : 1);
+        const int wring = occ2 ? 2 : 3;
+        const size_t lds = (size_t)(din + 1) * ib + (size_t)wring * a.w_buf_bytes + par_bytes;
+        const bool fits = occ2 ? (lds <= 81856 && ib <= (size_t)kB16MaxQ / 2 * kB16Waves * 1024)
+                               : (lds <= 160 * 1024 && ib <= (size_t)kB16MaxQ * kB16Waves * 1024);
+        if (!fits) continue;
+        pl->NT = nt; pl->occ2 = occ2; a.din = din; a.wring = wring; a.in_buf_bytes = (int)ib; pl->lds_bytes = lds;
+        found = true;
+    }
+    if (!found) return bad("conv2d_b16: LDS images exceed 160 KB");
     // weight image and grid
     const int G = a.G0 + a.G1;
     size_t woff = 0;
@@ -488,16 +536,19 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     return true;
 }
 
-template <int MT, int NT, bool GEN>
+template <int MT, int NT, bool GEN, bool OCC2>
 static hipError_t launch_b16(const B16Plan& pl, hipStream_t stream) {
     static bool raised = false;
+    const void* fn;
+    if constexpr (OCC2) fn = reinterpret_cast<const void*>(&conv_b16_kernel_occ2<MT, NT>);
+    else fn = reinterpret_cast<const void*>(&conv_b16_kernel<MT, NT, GEN>);
     if (!raised) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<MT, NT, GEN>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((conv_b16_kernel<MT, NT, GEN>), dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
+    if constexpr (OCC2) hipLaunchKernelGGL((conv_b16_kernel_occ2<MT, NT>), dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
+    else hipLaunchKernelGGL((conv_b16_kernel<MT, NT, GEN>), dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
     return hipGetLastError();
 }
 
@@ -570,10 +621,13 @@ int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* 
     const bool gen = d->act != UNETMI_ACT_NONE && d->act != UNETMI_ACT_LEAKY && d->act != UNETMI_ACT_RELU;
     if (gen && pl.MT > 1)
         return api_fail(UNETMI_E_UNSUPPORTED, "conv2d_b16: SiLU / Softplus / Sigmoid / Tanh / GELU epilogues are built for K <= 32 only");
-#define UNETMI_B16(MT_, NT_, GEN_) if (pl.MT == MT_ && pl.NT == NT_ && gen == GEN_) e = launch_b16<MT_, NT_, GEN_>(pl, st);
-    UNETMI_B16(1, 1, false) UNETMI_B16(1, 2, false) UNETMI_B16(2, 1, false) UNETMI_B16(2, 2, false)
-    UNETMI_B16(3, 1, false) UNETMI_B16(3, 2, false) UNETMI_B16(4, 1, false)
-    UNETMI_B16(1, 1, true) UNETMI_B16(1, 2, true)
+#define UNETMI_B16(MT_, NT_, GEN_, OCC_) \
+    if (pl.MT == MT_ && pl.NT == NT_ && gen == GEN_ && pl.occ2 == OCC_) e = launch_b16<MT_, NT_, GEN_, OCC_>(pl, st);
+    UNETMI_B16(1, 1, false, false) UNETMI_B16(1, 2, false, false) UNETMI_B16(2, 1, false, false) UNETMI_B16(2, 2, false, false)
+    UNETMI_B16(3, 1, false, false) UNETMI_B16(3, 2, false, false) UNETMI_B16(4, 1, false, false)
+    UNETMI_B16(1, 1, false, true) UNETMI_B16(1, 2, false, true) UNETMI_B16(2, 1, false, true) UNETMI_B16(2, 2, false, true)
+    UNETMI_B16(3, 1, false, true) UNETMI_B16(3, 2, false, true) UNETMI_B16(4, 1, false, true)
+    UNETMI_B16(1, 1, true, false) UNETMI_B16(1, 2, true, false)
 #undef UNETMI_B16
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("conv2d_b16 launch: ") + hipGetErrorString(e));
     return UNETMI_OK;
