@@ -54,11 +54,14 @@ constexpr int kB16MaxPhase = 4;
 constexpr int kB16Waves = 8;          // waves (= output rows) per workgroup
 constexpr int kB16MaxQ = 8;           // input DMA instructions per wave and group (64 KB image)
 
+// Column quantities come in pairs: a transposed layer with time stride 2 runs its two column phases as the
+// two column tiles of one workgroup ("pair" mode), so that the workgroup writes whole output lines; otherwise
+// entry 1 repeats entry 0.
 struct B16Phase {
-    int nth, ntw;            // taps of this phase
-    int offh, offw;          // ih = i*sih + t*tdh + offh
-    int poh, pow_;           // oh = i*soh + poh
-    int rows, cols;          // extent of this phase's output grid
+    int nth, ntw[2];         // taps of this phase
+    int offh, offw[2];       // ih = i*sih + t*tdh + offh
+    int poh, pow_[2];        // oh = i*soh + poh
+    int rows, cols[2];       // extent of this phase's output grid
     unsigned wg_end;         // workgroups up to and including this phase
     unsigned w_off;          // byte offset of the phase's weight image
     unsigned w_bytes;        // its size
@@ -73,6 +76,7 @@ struct B16Args {
     int sih, siw, tdh, tdw, soh, sow;
     int nphase, hl, din;     // weight halves (1 | 2); input prefetch distance in groups (1 | 2)
     int wring, allrows;      // weight ring depth (2 | 3); 1: one step holds every tap row of a group
+    int pair;                // 1: column tiles = the two column phases
     int in_buf_bytes, w_buf_bytes;
     int act, act_first, act_pc, out_nchw_f32;
     B16Phase ph[kB16MaxPhase];
@@ -121,18 +125,18 @@ __device__ __forceinline__ void b16_wait_vm(int n) {
 // Bias, folded BatchNorm, activation and gate on the fp32 accumulators, then either 8-byte stores of
 // four bfloat16 channels (lanes l and l+32 complete a pixel's 16-byte record, a wave writes 512
 // contiguous bytes per instruction) or plain fp32 NCHW stores for the heads.
-template <int MT, int NT, bool GEN>
-__device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], const B16Args& p, const float* s_par,
-                                             int n, int oh, int j0, int pcol, int pow_, int half, int j) {
+template <int MT, int NT, bool GEN, bool PAIR>
+__device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], const B16Args& p, const B16Phase& ph,
+                                             const float* s_par, int n, int oh, int j0, int half, int j) {
     const int CBo = 2 * ((p.K + 15) >> 4);
     const size_t OHW = (size_t)p.OH * p.OW;
     size_t pix[NT];
     bool ok[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int jc = j0 + nt * 32 + j;
-        ok[nt] = jc < pcol;
-        pix[nt] = (size_t)oh * p.OW + (size_t)(jc * p.sow + pow_);
+        const int jc = PAIR ? j0 + j : j0 + nt * 32 + j;
+        ok[nt] = jc < ph.cols[PAIR ? nt : 0];
+        pix[nt] = (size_t)oh * p.OW + (size_t)(jc * p.sow + ph.pow_[PAIR ? nt : 0]);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -146,9 +150,9 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
                 bi[r] = s_par[m0 + r]; sc[r] = s_par[MT * 32 + m0 + r]; sf[r] = s_par[2 * MT * 32 + m0 + r];
                 sl[r] = s_par[3 * MT * 32 + m0 + r]; gt[r] = s_par[4 * MT * 32 + m0 + r];
             }
+            float v[NT][4];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float v[4];
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = acc[mt][nt][q * 4 + r] + bi[r];
@@ -157,28 +161,40 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
                         x = x * sc[r] + sf[r];
                         x = GEN ? b16_act_general(x, p.act, sl[r]) : (x >= 0.f ? x : x * sl[r]);
                     }
-                    v[r] = x * gt[r];
+                    v[nt][r] = x * gt[r];
                 }
-                if (p.out_nchw_f32) {
+            if (p.out_nchw_f32) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (ok[nt] && m0 + r < p.K)
-                            static_cast<float*>(p.out)[((size_t)n * p.K + m0 + r) * OHW + pix[nt]] = v[r];
-                } else if (ok[nt] && blk < CBo) {
-                    uint2 w2;
-                    w2.x = b16_pack2(v[0], v[1]);
-                    w2.y = b16_pack2(v[2], v[3]);
-                    char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + pix[nt]) * 16 + half * 8;
-                    *reinterpret_cast<uint2*>(o) = w2;
+                            static_cast<float*>(p.out)[((size_t)n * p.K + m0 + r) * OHW + pix[nt]] = v[nt][r];
+            } else if constexpr (NT == 2) {
+                // lanes l and l+32 hold the two halves of a pixel's record in each column tile: swapping the upper
+                // lanes of tile 0 with the lower lanes of tile 1 leaves every lane with one whole 16-byte record
+                // (lanes 0..31: tile 0, lanes 32..63: tile 1)
+                const auto lo = __builtin_amdgcn_permlane32_swap(b16_pack2(v[0][0], v[0][1]), b16_pack2(v[1][0], v[1][1]), false, false);
+                const auto hi = __builtin_amdgcn_permlane32_swap(b16_pack2(v[0][2], v[0][3]), b16_pack2(v[1][2], v[1][3]), false, false);
+                if ((half ? ok[1] : ok[0]) && blk < CBo) {
+                    char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + (half ? pix[1] : pix[0])) * 16;
+                    *reinterpret_cast<uint4*>(o) = uint4{lo[0], hi[0], lo[1], hi[1]};
                 }
+            } else if (ok[0] && blk < CBo) {
+                uint2 w2;
+                w2.x = b16_pack2(v[0][0], v[0][1]);
+                w2.y = b16_pack2(v[0][2], v[0][3]);
+                char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + pix[0]) * 16 + half * 8;
+                *reinterpret_cast<uint2*>(o) = w2;
             }
         }
 }
 
 // OCC2: built for two workgroups per CU (128 registers, LDS images <= 80 KB, input image <= 32 KB), so one
 // workgroup's prologue and epilogue run under the other's matrix loop.
-template <int MT, int NT, bool GEN, bool OCC2>
+template <int MT, int NT, bool GEN, bool OCC2, bool PAIR>
 __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
+    static_assert(!PAIR || NT == 2, "pair mode uses both column tiles");
     constexpr int MAXQ = OCC2 ? kB16MaxQ / 2 : kB16MaxQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -198,23 +214,35 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     for (int q = 0; q < kB16MaxPhase - 1; ++q)
         if (q + 1 < p.nphase && bid >= p.ph[q].wg_end) { a = q + 1; start = p.ph[q].wg_end; }
     bid -= start;
-    const int nth = p.ph[a].nth, ntw = p.ph[a].ntw;
-    const int prow = p.ph[a].rows, pcol = p.ph[a].cols;
-    const int njt = (pcol + 32 * NT - 1) / (32 * NT), nit = (prow + kB16Waves - 1) / kB16Waves;
+    constexpr int TW = PAIR ? 32 : 32 * NT;            // columns of the phase grid per workgroup
+    const int nth = p.ph[a].nth, ntw0 = p.ph[a].ntw[0], ntw1 = p.ph[a].ntw[1];
+    const int ntws = PAIR ? ntw0 + ntw1 : ntw0;         // taps per tap row in the weight image
+    const int prow = p.ph[a].rows;
+    const int njt = (p.ph[a].cols[0] + TW - 1) / TW, nit = (prow + kB16Waves - 1) / kB16Waves;
     const int jt = bid % njt; bid /= njt;
     const int it = bid % nit;
     const int n = bid / nit;
-    const int i0 = it * kB16Waves, j0 = jt * 32 * NT;
+    const int i0 = it * kB16Waves, j0 = jt * TW;
 
-    const int spanh = (nth - 1) * p.tdh, spanw = (ntw - 1) * p.tdw;
-    const int negh = spanh < 0 ? spanh : 0, negw = spanw < 0 ? spanw : 0;
+    const int spanh = (nth - 1) * p.tdh;
+    const int negh = spanh < 0 ? spanh : 0;
     const int rows_in = (kB16Waves - 1) * p.sih + (spanh < 0 ? -spanh : spanh) + 1;
-    const int cols_in = (32 * NT - 1) * p.siw + (spanw < 0 ? -spanw : spanw) + 1;
+    // columns of the input image: the union of what the column tiles read
+    int wbase, wtop;
+    {
+        const int span0 = (ntw0 - 1) * p.tdw, span1 = (ntw1 - 1) * p.tdw;
+        const int lo0 = p.ph[a].offw[0] + (span0 < 0 ? span0 : 0), lo1 = p.ph[a].offw[1] + (span1 < 0 ? span1 : 0);
+        const int hi0 = (TW - 1) * p.siw + p.ph[a].offw[0] + (span0 > 0 ? span0 : 0);
+        const int hi1 = (TW - 1) * p.siw + p.ph[a].offw[1] + (span1 > 0 ? span1 : 0);
+        wbase = PAIR ? (lo0 < lo1 ? lo0 : lo1) : lo0;
+        wtop = PAIR ? (hi0 > hi1 ? hi0 : hi1) : hi0;
+    }
+    const int cols_in = wtop - wbase + 1;
     const int plane = rows_in * cols_in;
     const int slots = 2 * plane;
     const int n_in_instr = (slots + 63) >> 6;
     const int ihb = i0 * p.sih + p.ph[a].offh + negh;
-    const int iwb = j0 * p.siw + p.ph[a].offw + negw;
+    const int iwb = j0 * p.siw + wbase;
     const int HW = p.H * p.W;
 
     // ---- per-lane byte offsets of this wave's input DMA instructions (same for every group) ----
@@ -236,8 +264,8 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     const int G = p.G0 + p.G1;
     const int R = p.allrows ? nth : 1;               // tap rows per step
     const int nchunk = nth / R;
-    const int step_bytes = R * ntw * p.hl * MT * 1024;
-    const int n_w_instr = R * ntw * p.hl * MT;
+    const int step_bytes = R * ntws * p.hl * MT * 1024;
+    const int n_w_instr = R * ntws * p.hl * MT;
     const int S = G * nchunk;
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + p.ph[a].w_off), 0, (int)p.ph[a].w_bytes, 0x00020000);
 
@@ -300,7 +328,8 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
 
     int colb[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) colb[nt] = ((nt * 32 + j) * p.siw - negw) * 16;
+    for (int nt = 0; nt < NT; ++nt)
+        colb[nt] = ((PAIR ? j : nt * 32 + j) * p.siw + p.ph[a].offw[PAIR ? nt : 0] - wbase) * 16;
     const int a_lane = half * 512 + j * 16;
 
     int s = 0;
@@ -315,20 +344,40 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
                 const int th = tc * R + tr;
                 const int rowl = wave * p.sih + th * p.tdh - negh;
                 const char* brow = in_img + (half * plane + rowl * cols_in) * 16;
+                if constexpr (PAIR) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int ntw_n = nt ? ntw1 : ntw0;
+                        const char* wt0 = wimg + (tr * ntws + (nt ? ntw0 : 0)) * p.hl * MT * 1024;
 #pragma unroll 1
-                for (int tw = 0; tw < ((B16_ABLATE & 1) ? 0 : ntw); ++tw) {
-                    bf16x8 B[NT];
+                        for (int tw = 0; tw < ((B16_ABLATE & 1) ? 0 : ntw_n); ++tw) {
+                            const bf16x8 B = *reinterpret_cast<const bf16x8*>(brow + colb[nt] + tw * p.tdw * 16);
+                            for (int h = 0; h < p.hl; ++h) {
+                                const char* wt = wt0 + (tw * p.hl + h) * MT * 1024;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        B[nt] = *reinterpret_cast<const bf16x8*>(brow + colb[nt] + tw * p.tdw * 16);
-                    for (int h = 0; h < p.hl; ++h) {
-                        const char* wt = wimg + ((tr * ntw + tw) * p.hl + h) * MT * 1024;
+                                for (int mt = 0; mt < MT; ++mt) {
+                                    const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[mt][nt], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll 1
+                    for (int tw = 0; tw < ((B16_ABLATE & 1) ? 0 : ntw0); ++tw) {
+                        bf16x8 B[NT];
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
+                        for (int nt = 0; nt < NT; ++nt)
+                            B[nt] = *reinterpret_cast<const bf16x8*>(brow + colb[nt] + tw * p.tdw * 16);
+                        for (int h = 0; h < p.hl; ++h) {
+                            const char* wt = wimg + ((tr * ntws + tw) * p.hl + h) * MT * 1024;
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[nt], acc[mt][nt], 0, 0, 0);
+                            for (int mt = 0; mt < MT; ++mt) {
+                                const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[nt], acc[mt][nt], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -344,14 +393,20 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     const int i = i0 + wave;
     if (i >= prow) return;                              // wave-uniform
     const int oh = i * p.soh + p.ph[a].poh;
-    b16_epilogue<MT, NT, GEN>(acc, p, s_par, n, oh, j0, pcol, p.ph[a].pow_, half, j);
+    b16_epilogue<MT, NT, GEN, PAIR>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
 }
 
 template <int MT, int NT, bool GEN>
-__global__ __launch_bounds__(512, 2) void conv_b16_kernel(const B16Args p) { conv_b16_body<MT, NT, GEN, false>(p); }
+__global__ __launch_bounds__(512, 2) void conv_b16_kernel(const B16Args p) { conv_b16_body<MT, NT, GEN, false, false>(p); }
 
 template <int MT, int NT>
-__global__ __launch_bounds__(512, 4) void conv_b16_kernel_occ2(const B16Args p) { conv_b16_body<MT, NT, false, true>(p); }
+__global__ __launch_bounds__(512, 4) void conv_b16_kernel_occ2(const B16Args p) { conv_b16_body<MT, NT, false, true, false>(p); }
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void conv_b16_kernel_pair(const B16Args p) { conv_b16_body<MT, 2, false, false, true>(p); }
+
+template <int MT>
+__global__ __launch_bounds__(512, 4) void conv_b16_kernel_pair_occ2(const B16Args p) { conv_b16_body<MT, 2, false, true, true>(p); }
 
 // ---- layout conversion ------------------------------------------------------------------------
 // NCHW (fp32 or bfloat16) -> blocked; a thread owns one pixel of one 8-channel block.
@@ -394,8 +449,9 @@ struct B16Plan {
     int MT, NT;
     bool occ2;
     unsigned grid;
+    int kw0[kB16MaxPhase][2];
     size_t lds_bytes, packed_bytes;
-    int kh0[kB16MaxPhase], kw0[kB16MaxPhase], khs, kws;      // kernel index of tap t: k0 + t * ks
+    int kh0[kB16MaxPhase], khs, kws;                         // kernel index of tap t: k0 + t * ks
 };
 
 static unsigned short host_bf16(float v) {
@@ -442,11 +498,14 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     if (pl->MT > 4) return bad("conv2d_b16: more than 128 output channels");
     if ((size_t)2 * std::max(a.G0, a.G1) * d.H * d.W * 16 >= (size_t)1 << 31) return bad("conv2d_b16: sample larger than 2 GB");
     int np = 0;
+    // a time-stride-2 transposed layer runs its two column phases as the two column tiles of a workgroup
+    a.pair = (d.transposed && d.sw == 2 && pl->MT <= 3 && !(d.act != UNETMI_ACT_NONE && d.act != UNETMI_ACT_LEAKY && d.act != UNETMI_ACT_RELU)) ? 1 : 0;
     if (!d.transposed) {
         a.sih = d.sh; a.siw = d.sw; a.tdh = d.dh; a.tdw = d.dw; a.soh = 1; a.sow = 1;
         B16Phase& p = a.ph[0];
-        p.nth = d.kh; p.ntw = d.kw; p.offh = -d.ph; p.offw = -d.pw; p.poh = 0; p.pow_ = 0; p.rows = OH; p.cols = OW;
-        pl->kh0[0] = 0; pl->kw0[0] = 0; pl->khs = 1; pl->kws = 1;
+        p.nth = d.kh; p.offh = -d.ph; p.poh = 0; p.rows = OH;
+        for (int c = 0; c < 2; ++c) { p.ntw[c] = d.kw; p.offw[c] = -d.pw; p.pow_[c] = 0; p.cols[c] = OW; pl->kw0[0][c] = 0; }
+        pl->kh0[0] = 0; pl->khs = 1; pl->kws = 1;
         np = 1;
     } else {
         if (d.sh * d.sw > kB16MaxPhase) return bad("conv2d_b16: more than 4 output phases");
@@ -455,19 +514,26 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         a.tdh = d.sh == 1 ? -d.dh : -1; a.tdw = d.sw == 1 ? -d.dw : -1;
         pl->khs = d.sh; pl->kws = d.sw;
         for (int ah = 0; ah < d.sh; ++ah)
-            for (int aw = 0; aw < d.sw; ++aw) {
+            for (int aw = 0; aw < (a.pair ? 1 : d.sw); ++aw) {
                 B16Phase& p = a.ph[np];
-                const int kh0 = (ah + d.ph) % d.sh, kw0 = (aw + d.pw) % d.sw;
+                const int kh0 = (ah + d.ph) % d.sh;
                 p.nth = kh0 < d.kh ? (d.kh - kh0 + d.sh - 1) / d.sh : 0;
-                p.ntw = kw0 < d.kw ? (d.kw - kw0 + d.sw - 1) / d.sw : 0;
-                if (p.nth < 1 || p.ntw < 1) return bad("conv2d_b16: an output phase without taps (kernel smaller than stride)");
                 // oh = ih*s - p + k*d  ->  ih = (oh + p - k*d) / s ; with oh = i*s + a and k = k0 + t*s (d = 1 when s > 1)
                 p.offh = d.sh == 1 ? d.ph : (ah + d.ph - kh0) / d.sh;
-                p.offw = d.sw == 1 ? d.pw : (aw + d.pw - kw0) / d.sw;
-                p.poh = ah; p.pow_ = aw;
+                p.poh = ah;
                 p.rows = OH > ah ? (OH - ah + d.sh - 1) / d.sh : 0;
-                p.cols = OW > aw ? (OW - aw + d.sw - 1) / d.sw : 0;
-                pl->kh0[np] = kh0; pl->kw0[np] = kw0;
+                pl->kh0[np] = kh0;
+                for (int c = 0; c < 2; ++c) {
+                    const int awc = a.pair ? c : aw;
+                    const int kw0 = (awc + d.pw) % d.sw;
+                    p.ntw[c] = kw0 < d.kw ? (d.kw - kw0 + d.sw - 1) / d.sw : 0;
+                    p.offw[c] = d.sw == 1 ? d.pw : (awc + d.pw - kw0) / d.sw;
+                    p.pow_[c] = awc;
+                    p.cols[c] = OW > awc ? (OW - awc + d.sw - 1) / d.sw : 0;
+                    pl->kw0[np][c] = kw0;
+                    if (p.ntw[c] < 1) return bad("conv2d_b16: an output phase without taps (kernel smaller than stride)");
+                }
+                if (p.nth < 1) return bad("conv2d_b16: an output phase without taps (kernel smaller than stride)");
                 ++np;
             }
     }
@@ -476,20 +542,31 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     // one workgroup's prologue / epilogue hidden under the other's matrix loop) with two column tiles, then with
     // one; else one workgroup per CU with a ring of 3.  A step takes every tap row of a channel group when
     // those weights are at most 24 KB (kernels one column wide would otherwise hit a barrier every few MFMAs).
-    int max_nth = 0, max_ntw = 0;
+    int max_nth = 0, max_ntws = 0;                 // max_ntws: taps per tap row in the weight image
     bool one_row_phase = false;
     for (int q = 0; q < np; ++q) {
-        max_nth = std::max(max_nth, a.ph[q].nth); max_ntw = std::max(max_ntw, a.ph[q].ntw);
+        max_nth = std::max(max_nth, a.ph[q].nth);
+        max_ntws = std::max(max_ntws, a.pair ? a.ph[q].ntw[0] + a.ph[q].ntw[1] : a.ph[q].ntw[0]);
         if (a.ph[q].nth == 1) one_row_phase = true;
     }
-    a.allrows = (max_nth > 1 && max_nth * max_ntw * hl * pl->MT <= 24) ? 1 : 0;
+    a.allrows = (max_nth > 1 && max_nth * max_ntws * hl * pl->MT <= 24) ? 1 : 0;
     const bool single_step_group = a.allrows || one_row_phase;
-    auto in_bytes = [&](int nt) {
+    auto in_bytes = [&](int nt) {                  // largest input image of a channel group over the phases
+        const int tw_cols = a.pair ? 32 : 32 * nt;
+        int cols_in = 1;
+        for (int q = 0; q < np; ++q) {
+            int lo = 1 << 30, hi = -(1 << 30);
+            for (int c = 0; c < (a.pair ? 2 : 1); ++c) {
+                const int span = (a.ph[q].ntw[c] - 1) * a.tdw;
+                lo = std::min(lo, a.ph[q].offw[c] + std::min(span, 0));
+                hi = std::max(hi, (tw_cols - 1) * a.siw + a.ph[q].offw[c] + std::max(span, 0));
+            }
+            cols_in = std::max(cols_in, hi - lo + 1);
+        }
         const int rows_in = (kB16Waves - 1) * a.sih + (max_nth - 1) * std::abs(a.tdh) + 1;
-        const int cols_in = (32 * nt - 1) * a.siw + (max_ntw - 1) * std::abs(a.tdw) + 1;
         return (size_t)(((2 * rows_in * cols_in + 63) / 64) * 1024);
     };
-    a.w_buf_bytes = (a.allrows ? max_nth : 1) * max_ntw * hl * pl->MT * 1024;
+    a.w_buf_bytes = (a.allrows ? max_nth : 1) * max_ntws * hl * pl->MT * 1024;
     const size_t par_bytes = 5 * pl->MT * 32 * 4;
     const bool general_act = d.act != UNETMI_ACT_NONE && d.act != UNETMI_ACT_LEAKY && d.act != UNETMI_ACT_RELU;
     int force_nt = 0, force_occ = -1;
@@ -502,8 +579,9 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         const int nt = (c & 1) ? 1 : 2;
         const bool occ2 = c < 2;
         if (nt == 2 && pl->MT > 3) continue;
+        if (a.pair && nt != 2) continue;
         if (occ2 && general_act) continue;
-        if (force_nt && nt != force_nt) continue;
+        if (force_nt && nt != force_nt && !a.pair) continue;
         if (force_occ >= 0 && (int)occ2 != force_occ) continue;
         const size_t ib = in_bytes(nt);
         const int din = occ2 ? 1 : (single_step_group ? 2 : 1);
@@ -523,9 +601,11 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     for (int q = 0; q < np; ++q) {
         B16Phase& p = a.ph[q];
         p.w_off = (unsigned)woff;
-        p.w_bytes = (unsigned)((size_t)G * p.nth * p.ntw * hl * pl->MT * 1024);
+        const int ntws = a.pair ? p.ntw[0] + p.ntw[1] : p.ntw[0];
+        p.w_bytes = (unsigned)((size_t)G * p.nth * ntws * hl * pl->MT * 1024);
         woff += p.w_bytes;
-        const unsigned long long njt = (p.cols + 32 * pl->NT - 1) / (32 * pl->NT), nit = (p.rows + kB16Waves - 1) / kB16Waves;
+        const int tw_cols = a.pair ? 32 : 32 * pl->NT;
+        const unsigned long long njt = (p.cols[0] + tw_cols - 1) / tw_cols, nit = (p.rows + kB16Waves - 1) / kB16Waves;
         wg += njt * nit * (unsigned long long)d.N;
         p.wg_end = (unsigned)wg;
     }
@@ -536,19 +616,15 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     return true;
 }
 
-template <int MT, int NT, bool GEN, bool OCC2>
-static hipError_t launch_b16(const B16Plan& pl, hipStream_t stream) {
-    static bool raised = false;
-    const void* fn;
-    if constexpr (OCC2) fn = reinterpret_cast<const void*>(&conv_b16_kernel_occ2<MT, NT>);
-    else fn = reinterpret_cast<const void*>(&conv_b16_kernel<MT, NT, GEN>);
-    if (!raised) {
-        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+template <typename Kernel>
+static hipError_t launch_b16(Kernel kernel, bool* raised, const B16Plan& pl, hipStream_t stream) {
+    if (!*raised) {                    // dynamic LDS beyond 64 KB has to be requested once per kernel
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        raised = true;
+        *raised = true;
     }
-    if constexpr (OCC2) hipLaunchKernelGGL((conv_b16_kernel_occ2<MT, NT>), dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
-    else hipLaunchKernelGGL((conv_b16_kernel<MT, NT, GEN>), dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
+    hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
     return hipGetLastError();
 }
 
@@ -577,26 +653,30 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
     for (int q = 0; q < a.nphase; ++q) {
         const B16Phase& p = a.ph[q];
         unsigned short* img = reinterpret_cast<unsigned short*>(static_cast<char*>(packed) + p.w_off);
+        const int ncp = a.pair ? 2 : 1;
+        const int ntws = a.pair ? p.ntw[0] + p.ntw[1] : p.ntw[0];
         for (int g = 0; g < G; ++g)
             for (int th = 0; th < p.nth; ++th)
-                for (int tw = 0; tw < p.ntw; ++tw) {
-                    const int ky = pl.kh0[q] + th * pl.khs, kx = pl.kw0[q] + tw * pl.kws;
-                    for (int h = 0; h < a.hl; ++h)
-                        for (int mt = 0; mt < MT; ++mt)
-                            for (int hf = 0; hf < 2; ++hf)
-                                for (int row = 0; row < 32; ++row)
-                                    for (int k = 0; k < 8; ++k) {
-                                        const size_t dst = ((((((size_t)(g * p.nth + th) * p.ntw + tw) * a.hl + h) * MT + mt) * 2 + hf) * 32 + row) * 8 + k;
-                                        const int cl = (g < a.G0 ? g : g - a.G0) * 16 + hf * 8 + k;
-                                        const int ci = g < a.G0 ? (cl < d->C0 ? cl : -1) : (cl < d->C1 ? d->C0 + cl : -1);
-                                        const int co = mt * 32 + row;
-                                        if (ci < 0 || co >= K) continue;
-                                        const size_t src = d->transposed ? (((size_t)ci * K + co) * KH + ky) * KW + kx
-                                                                         : (((size_t)co * C + ci) * KH + ky) * KW + kx;
-                                        const unsigned short hi = host_bf16(w[src]);
-                                        img[dst] = h == 0 ? hi : host_bf16(w[src] - host_bf16_to_f32(hi));
-                                    }
-                }
+                for (int cp = 0; cp < ncp; ++cp)
+                    for (int tw = 0; tw < p.ntw[cp]; ++tw) {
+                        const int ky = pl.kh0[q] + th * pl.khs, kx = pl.kw0[q][cp] + tw * pl.kws;
+                        const size_t tap = (size_t)(g * p.nth + th) * ntws + (cp ? p.ntw[0] : 0) + tw;
+                        for (int h = 0; h < a.hl; ++h)
+                            for (int mt = 0; mt < MT; ++mt)
+                                for (int hf = 0; hf < 2; ++hf)
+                                    for (int row = 0; row < 32; ++row)
+                                        for (int k = 0; k < 8; ++k) {
+                                            const size_t dst = (((((tap * a.hl + h) * MT + mt) * 2 + hf) * 32 + row) * 8) + k;
+                                            const int cl = (g < a.G0 ? g : g - a.G0) * 16 + hf * 8 + k;
+                                            const int ci = g < a.G0 ? (cl < d->C0 ? cl : -1) : (cl < d->C1 ? d->C0 + cl : -1);
+                                            const int co = mt * 32 + row;
+                                            if (ci < 0 || co >= K) continue;
+                                            const size_t src = d->transposed ? (((size_t)ci * K + co) * KH + ky) * KW + kx
+                                                                             : (((size_t)co * C + ci) * KH + ky) * KW + kx;
+                                            const unsigned short hi = host_bf16(w[src]);
+                                            img[dst] = h == 0 ? hi : host_bf16(w[src] - host_bf16_to_f32(hi));
+                                        }
+                    }
     }
     return UNETMI_OK;
 }
@@ -621,13 +701,25 @@ int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* 
     const bool gen = d->act != UNETMI_ACT_NONE && d->act != UNETMI_ACT_LEAKY && d->act != UNETMI_ACT_RELU;
     if (gen && pl.MT > 1)
         return api_fail(UNETMI_E_UNSUPPORTED, "conv2d_b16: SiLU / Softplus / Sigmoid / Tanh / GELU epilogues are built for K <= 32 only");
-#define UNETMI_B16(MT_, NT_, GEN_, OCC_) \
-    if (pl.MT == MT_ && pl.NT == NT_ && gen == GEN_ && pl.occ2 == OCC_) e = launch_b16<MT_, NT_, GEN_, OCC_>(pl, st);
-    UNETMI_B16(1, 1, false, false) UNETMI_B16(1, 2, false, false) UNETMI_B16(2, 1, false, false) UNETMI_B16(2, 2, false, false)
-    UNETMI_B16(3, 1, false, false) UNETMI_B16(3, 2, false, false) UNETMI_B16(4, 1, false, false)
-    UNETMI_B16(1, 1, false, true) UNETMI_B16(1, 2, false, true) UNETMI_B16(2, 1, false, true) UNETMI_B16(2, 2, false, true)
-    UNETMI_B16(3, 1, false, true) UNETMI_B16(3, 2, false, true) UNETMI_B16(4, 1, false, true)
-    UNETMI_B16(1, 1, true, false) UNETMI_B16(1, 2, true, false)
+#define UNETMI_B16(MT_, NT_, GEN_)                                                                          \
+    if (!pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && gen == GEN_ && !pl.occ2) {                         \
+        static bool raised = false; e = launch_b16(&conv_b16_kernel<MT_, NT_, GEN_>, &raised, pl, st); }
+#define UNETMI_B16_OCC2(MT_, NT_)                                                                           \
+    if (!pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && !gen && pl.occ2) {                                 \
+        static bool raised = false; e = launch_b16(&conv_b16_kernel_occ2<MT_, NT_>, &raised, pl, st); }
+#define UNETMI_B16_PAIR(MT_)                                                                                \
+    if (pl.args.pair && pl.MT == MT_ && !pl.occ2) {                                                         \
+        static bool raised = false; e = launch_b16(&conv_b16_kernel_pair<MT_>, &raised, pl, st); }          \
+    if (pl.args.pair && pl.MT == MT_ && pl.occ2) {                                                          \
+        static bool raised = false; e = launch_b16(&conv_b16_kernel_pair_occ2<MT_>, &raised, pl, st); }
+    UNETMI_B16(1, 1, false) UNETMI_B16(1, 2, false) UNETMI_B16(2, 1, false) UNETMI_B16(2, 2, false)
+    UNETMI_B16(3, 1, false) UNETMI_B16(3, 2, false) UNETMI_B16(4, 1, false)
+    UNETMI_B16(1, 1, true) UNETMI_B16(1, 2, true)
+    UNETMI_B16_OCC2(1, 1) UNETMI_B16_OCC2(1, 2) UNETMI_B16_OCC2(2, 1) UNETMI_B16_OCC2(2, 2)
+    UNETMI_B16_OCC2(3, 1) UNETMI_B16_OCC2(3, 2) UNETMI_B16_OCC2(4, 1)
+    UNETMI_B16_PAIR(1) UNETMI_B16_PAIR(2) UNETMI_B16_PAIR(3)
+#undef UNETMI_B16_OCC2
+#undef UNETMI_B16_PAIR
 #undef UNETMI_B16
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("conv2d_b16 launch: ") + hipGetErrorString(e));
     return UNETMI_OK;
