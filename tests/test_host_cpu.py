@@ -198,3 +198,55 @@ def test_gradient_bucket_all_reduce_two_ranks_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def _bf16_bits(x):
+    """Nearest-even bfloat16 bit patterns of a float32 array (numpy restatement of the packer's rounding)."""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = u + 0x7FFF + ((u >> 16) & 1)
+    return ((u >> 16) & 0xFFFF).astype(np.uint16)
+
+
+def test_b16_weight_image_layout():
+    """unetmi_conv2d_b16_pack_weights (a host function): the image is
+    [phase][16-channel group][tap row][column phase][tap col][half][32-channel tile][k half][row][8 k],
+    channels of the two concat sources padded separately to multiples of 16, transposed layers split into
+    stride phases with the taps of each phase only."""
+    import torch
+    from unet_amd.blocked import pack_b16_weights
+    rng = np.random.default_rng(7)
+    # plain convolution, concat input 20 + 12 channels, 40 outputs, two weight halves
+    C0, C1, K, kh, kw = 20, 12, 40, 3, 2
+    w = rng.standard_normal((K, C0 + C1, kh, kw)).astype(np.float32)
+    img = pack_b16_weights(torch.from_numpy(w), C0, C1, [K, kh, kw, 1, 1, 1, 0, 1, 1, 0, 0], 0, halves=2).numpy().view(np.uint16)
+    G0, G1, MT = 2, 1, 2
+    assert img.size == (G0 + G1) * kh * kw * 2 * MT * 2 * 32 * 8
+    img = img.reshape(G0 + G1, kh, kw, 2, MT, 2, 32, 8)
+    hi = _bf16_bits(w)
+    lo = _bf16_bits(w - (hi.astype(np.uint32) << 16).view(np.float32))
+    for g, hf, k, co in [(0, 0, 0, 0), (0, 1, 7, 39), (1, 0, 3, 17), (1, 0, 4, 5), (2, 0, 5, 33), (2, 1, 3, 8), (2, 1, 4, 8), (0, 0, 1, 40)]:
+        cl = (g if g < G0 else g - G0) * 16 + hf * 8 + k
+        ci = (cl if cl < C0 else -1) if g < G0 else (C0 + cl if cl < C1 else -1)
+        for th in range(kh):
+            for tw in range(kw):
+                got = img[g, th, tw, :, co // 32, hf, co % 32, k]
+                if ci < 0 or co >= K:
+                    assert got[0] == 0 and got[1] == 0
+                else:
+                    assert got[0] == hi[co, ci, th, tw] and got[1] == lo[co, ci, th, tw]
+    # transposed, stride (2,2), kernel 5x3, padding (2,1): row phases {kh0=0: 3 taps, kh0=1: 2 taps}, each holding
+    # both column phases (column phase 0 starts at kw0 = 1: one tap; column phase 1 at kw0 = 0: two taps)
+    C, K = 16, 32
+    wt = rng.standard_normal((C, K, 5, 3)).astype(np.float32)
+    img = pack_b16_weights(torch.from_numpy(wt), C, 0, [K, 5, 3, 2, 2, 2, 1, 1, 1, 0, 1], 1).numpy().view(np.uint16)
+    hb = _bf16_bits(wt)
+    # phase ah=0: kh0 = (0+2)%2 = 0 -> ky 0,2,4 ; phase ah=1: kh0 = 1 -> ky 1,3.  Tap row layout [cp0 taps | cp1 taps].
+    n0 = 1 * 3 * 3 * 1 * 1 * 2 * 32 * 8
+    ph0 = img[:n0].reshape(3, 3, 2, 32, 8)          # [th][cp0: kx=1 | cp1: kx=0, kx=2][half][row][k]
+    ph1 = img[n0:].reshape(2, 3, 2, 32, 8)
+    for th, ky in enumerate((0, 2, 4)):
+        for slot, kx in enumerate((1, 0, 2)):
+            assert np.array_equal(ph0[th, slot, 1, :, 2], hb[10, :, ky, kx])    # channel 8 + 2, all 32 outputs
+    for th, ky in enumerate((1, 3)):
+        for slot, kx in enumerate((1, 0, 2)):
+            assert np.array_equal(ph1[th, slot, 0, :, 5], hb[5, :, ky, kx])
