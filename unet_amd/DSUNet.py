@@ -333,7 +333,7 @@ class DSUNet(nn.Module):
         """BlockedConv per encoder / decoder / head, or False when a layer is outside that kernel."""
         if self._blocked is None:
             from .blocked import BlockedConv
-            ok = isinstance(self.BTN, nn.Identity) and activation_code(self.mask.squash) is not None
+            ok = isinstance(self.BTN, nn.Identity)
             for m in list(self.encoders) + list(self.decoders):
                 conv = getattr(m, "conv", None) if isinstance(m, Encoder) else getattr(m, "transconv", None)
                 code = activation_code(m.relu)        # the wide layers' epilogue has LeakyReLU / PReLU / ReLU only
@@ -345,7 +345,9 @@ class DSUNet(nn.Module):
             if ok:
                 built = dict(enc=[BlockedConv(m.conv, m.bn, m.relu) for m in self.encoders],
                              dec=[BlockedConv(m.transconv, m.bn, m.relu) for m in self.decoders],
-                             head=BlockedConv(self.linear, None, self.mask.squash, nchw_out=True))
+                             # the head writes its two channels as fp32 NCHW; the squash runs on that small
+                             # tensor (inlined per accumulator, the transcendental epilogue doubles the launch)
+                             head=BlockedConv(self.linear, None, None, nchw_out=True))
             object.__setattr__(self, "_blocked", built)
         return self._blocked
 
@@ -359,7 +361,9 @@ class DSUNet(nn.Module):
             x = enc(x, None, self.attractEncoders[i](attract).float().contiguous())
         for i, dec in enumerate(layers["dec"]):
             x = dec(x, None if i == 0 else skips[L - i])
-        m = layers["head"](x)                                          # fp32 [B, 2, F, T], squashed
+        m = layers["head"](x)                                          # fp32 [B, 2, F, T]
+        if self.mask.squash is not None:
+            m = self.mask.squash(m)
         return torch.complex(m[:, 0, ...], m[:, 1, ...])
 
     def forward(self, sf, SV, theta):
