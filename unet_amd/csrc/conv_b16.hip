@@ -549,8 +549,13 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         max_ntws = std::max(max_ntws, a.pair ? a.ph[q].ntw[0] + a.ph[q].ntw[1] : a.ph[q].ntw[0]);
         if (a.ph[q].nth == 1) one_row_phase = true;
     }
-    a.allrows = (max_nth > 1 && max_nth * max_ntws * hl * pl->MT <= 24) ? 1 : 0;
-    const bool single_step_group = a.allrows || one_row_phase;
+    // Few workgroups (the deep layers): nothing else runs on a CU to cover a step's DMA latency, so take fewer,
+    // larger steps -- a whole channel group at a time while its weights stay within 48 KB.
+    unsigned long long wg64 = 0;
+    for (int q = 0; q < np; ++q)
+        wg64 += (unsigned long long)d.N * ((a.ph[q].rows + kB16Waves - 1) / kB16Waves) * ((a.ph[q].cols[0] + 63) / 64);
+    const bool few_wg = wg64 <= 512;
+    const bool allrows_ok = max_nth > 1 && max_nth * max_ntws * hl * pl->MT <= (few_wg ? 48 : 24);
     auto in_bytes = [&](int nt) {                  // largest input image of a channel group over the phases
         const int tw_cols = a.pair ? 32 : 32 * nt;
         int cols_in = 1;
@@ -566,7 +571,6 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         const int rows_in = (kB16Waves - 1) * a.sih + (max_nth - 1) * std::abs(a.tdh) + 1;
         return (size_t)(((2 * rows_in * cols_in + 63) / 64) * 1024);
     };
-    a.w_buf_bytes = (a.allrows ? max_nth : 1) * max_ntws * hl * pl->MT * 1024;
     const size_t par_bytes = 5 * pl->MT * 32 * 4;
     const bool general_act = d.act != UNETMI_ACT_NONE && d.act != UNETMI_ACT_LEAKY && d.act != UNETMI_ACT_RELU;
     int force_nt = 0, force_occ = -1;
@@ -575,17 +579,22 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         if (e[1] == ',' && e[2]) force_occ = e[2] - '0';
     }
     bool found = false;
-    for (int c = 0; c < 4 && !found; ++c) {
+    for (int cc = allrows_ok ? 0 : 6; cc < 12 && !found; ++cc) {      // first with whole-group steps, then without
+        const int c = cc % 6;                       // 4, 5: one workgroup per CU with rings of 2 (large steps)
+        a.allrows = cc < 6 ? 1 : 0;
+        a.w_buf_bytes = (a.allrows ? max_nth : 1) * max_ntws * hl * pl->MT * 1024;
+        const bool single_step_group = a.allrows || one_row_phase;
         const int nt = (c & 1) ? 1 : 2;
         const bool occ2 = c < 2;
+        const bool shallow = c >= 4;
         if (nt == 2 && pl->MT > 3) continue;
         if (a.pair && nt != 2) continue;
         if (occ2 && general_act) continue;
         if (force_nt && nt != force_nt && !a.pair) continue;
         if (force_occ >= 0 && (int)occ2 != force_occ) continue;
         const size_t ib = in_bytes(nt);
-        const int din = occ2 ? 1 : (single_step_group ? 2 : 1);
-        const int wring = occ2 ? 2 : 3;
+        const int din = (occ2 || shallow) ? 1 : (single_step_group ? 2 : 1);
+        const int wring = (occ2 || shallow) ? 2 : 3;
         const size_t lds = (size_t)(din + 1) * ib + (size_t)wring * a.w_buf_bytes + par_bytes;
         const bool fits = occ2 ? (lds <= 81856 && ib <= (size_t)kB16MaxQ / 2 * kB16Waves * 1024)
                                : (lds <= 160 * 1024 && ib <= (size_t)kB16MaxQ * kB16Waves * 1024);
