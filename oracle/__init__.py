@@ -2,7 +2,7 @@
 
 This package is the parity checker for the HIP path in ``unet_amd``: plain
 ``torch.nn`` CPU modules that restate, layer for layer, what the reference's
-``UNet`` / ``cRFUNet.UNet20`` / ``ResUNet`` / ``DSUNet`` compute.  It is imported
+``UNet`` / ``cRFUNet.UNet20`` / ``ResUNet`` / ``DSUNet`` / ``UDSS`` compute.  It is imported
 only by ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 ``bench.py``.  Nothing under ``unet_amd/`` imports it and the product never
 routes a forward through it.
@@ -21,10 +21,12 @@ from .nets import UNet, UNet20, ResUNet, ResUNetOnFreq, DSUNet
 from .tables import unet20_layers, default_unet, dsunet_architecture
 from .masking import crf_apply, resunet_mask_apply, crm_apply
 from .helper import DSUNet_helper
+from .udss import UDSS, ComplexConv2d, ComplexConvTranspose2d, ComplexBatchNorm2d
 
 __all__ = [
     "Encoder", "Decoder", "ResBlock", "DSEncoder", "DSDecoder", "Attractor",
     "AttractEncoder", "CRM", "CRM_sig", "CRM_soft", "CM", "GConv", "TrGConv", "TGRUBlock", "SEBlock", "UNet", "UNet20", "ResUNet", "ResUNetOnFreq", "DSUNet",
     "unet20_layers", "default_unet", "dsunet_architecture",
     "crf_apply", "resunet_mask_apply", "crm_apply", "DSUNet_helper",
+    "UDSS", "ComplexConv2d", "ComplexConvTranspose2d", "ComplexBatchNorm2d",
 ]

@@ -313,6 +313,35 @@ def main():
     if out is not None:
         save("dsunet_helper_eval", out=y_ref.numpy())
 
+    # ---------------------------------------------------------------- UDSS (complex-valued family)
+    import UDSS as R_udss
+    udss_out = {}
+    for label, kw in (("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU"))):
+        print("UDSS(type_norm='BatchNorm2d', {}), B=2 C=4 F=257 T=16 complex".format(kw))
+        ref = R_udss.UDSS(type_norm="BatchNorm2d", **kw)
+        seeded_fill_(ref, seed=61)
+        mine = oracle.UDSS(type_norm="BatchNorm2d", **kw)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+        sf = normal("udss/sf", (2, 4, 257, 16, 2), seed=61)
+        SV = normal("udss/SV", (2, 4, 514), seed=61)
+        ang = uniform("udss/theta", (2,), 0.0, 2 * np.pi, seed=61)
+        theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+        ref.eval(), mine.eval()
+        with torch.no_grad():
+            y_ref, y_mine = ref(sf, SV, theta), mine(sf, SV, theta)
+        require_equal(y_ref, y_mine, "UDSS " + label)
+        assert tuple(y_ref.shape) == (2, 257, 16) and y_ref.dtype == torch.complex64
+        udss_out[label] = torch.view_as_real(y_ref).numpy()
+    if out is not None:
+        save("udss_eval", **udss_out)
+    try:
+        R_udss.UDSS()
+        udss_default = "ok"
+    except Exception as e:  # noqa: BLE001
+        udss_default = type(e).__name__
+    print("  UDSS() with its default type_norm:", udss_default)
+
     # ------------------------------------------------- negative behaviours (kept as facts)
     print("negative behaviours of the reference")
     facts = {}
@@ -341,6 +370,7 @@ def main():
             facts["ResUNetOnFreq2_" + bn_kind] = "ok"
         except Exception as e:  # noqa: BLE001
             facts["ResUNetOnFreq2_" + bn_kind] = type(e).__name__
+    facts["UDSS_default_type_norm"] = udss_default
     print("  ", facts)
     assert facts["UNet_without_global"] == "NameError" and facts["UNet10"] == "TypeError"
     print("all oracle-vs-reference checks passed")

@@ -132,6 +132,57 @@ def test_resunet_onfreq_matches_golden_and_oracle(device):
         assert_close(dev.output(got, x.to(device)), ref.output(want, x), what="ResUNetOnFreq.output")
 
 
+@pytest.mark.parametrize("label,kw", [("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU"))])
+def test_udss_matches_golden_and_oracle(device, label, kw):
+    """The complex-valued family: every complex conv / transposed conv (+ both BatchNorms, activation, gate,
+    skip concat) is one real-convolution launch on the stacked [re | im] tensor."""
+    import numpy as np
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.UDSS(type_norm="BatchNorm2d", **kw).eval()
+    unet_amd.seeded_fill_(ref, seed=61)
+    dev = unet_amd.UDSS(type_norm="BatchNorm2d", **kw)
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    assert list(dev.state_dict().keys()) == list(ref.state_dict().keys())
+    dev.eval().to(device)
+    sf = normal("udss/sf", (2, 4, 257, 16, 2), seed=61)
+    SV = normal("udss/SV", (2, 4, 514), seed=61)
+    ang = uniform("udss/theta", (2,), 0.0, 2 * np.pi, seed=61)
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    with torch.no_grad():
+        want = ref(sf, SV, theta)
+        got = dev(sf.to(device), SV.to(device), theta.to(device))
+    assert got.dtype == torch.complex64 and tuple(got.shape) == (2, 257, 16)
+    assert_close(got, want, what="UDSS {} HIP vs oracle".format(label))
+    assert_close(torch.view_as_real(got.cpu()), torch.from_numpy(load_golden("udss_eval")[label]),
+                 what="UDSS {} HIP vs golden".format(label))
+    X = torch.complex(normal("udss/Xr", (2, 257, 16), seed=62), normal("udss/Xi", (2, 257, 16), seed=62))
+    assert_close(dev.masking(X.to(device), got), ref.masking(X, want), what="UDSS masking")
+
+
+def test_udss_blocks_and_errors(device):
+    """The complex blocks on their own ([B,C,F,T,2] in and out) and the constructor's error behaviour."""
+    import oracle.udss as O
+    import unet_amd
+    import importlib
+    D = importlib.import_module("unet_amd.UDSS")     # the package attribute of that name is the class
+    from unet_amd.seeding import normal
+    x = normal("udss/blk", (2, 6, 19, 23, 2), seed=63)
+    for ref, dev in ((O.UEncoder(6, 10, (5, 3), (2, 1), (2, 1)), D.Encoder(6, 10, (5, 3), (2, 1), (2, 1))),
+                     (O.UDecoder(6, 7, (5, 3), (2, 2), (0, 1), (2, 1)), D.Decoder(6, 7, (5, 3), (2, 2), (0, 1), (2, 1))),
+                     (O.ComplexConv2d(6, 3, 1), D.ComplexConv2d(6, 3, 1))):
+        unet_amd.seeded_fill_(ref, seed=64)
+        dev.load_state_dict(ref.state_dict(), strict=True)
+        ref.eval(), dev.eval().to(device)
+        with torch.no_grad():
+            assert_close(dev(x.to(device)), ref(x), what=type(dev).__name__)
+    with pytest.raises(UnboundLocalError):
+        unet_amd.UDSS()                                   # the reference's default type_norm is misspelt
+    with pytest.raises(Exception):
+        unet_amd.UDSS(type_norm="BatchNorm2d", type_encoder="ComplexDepthSeparable")
+
+
 def test_pointwise_kernels(device):
     """LayerNorm over frequency, tanh mask, complex ratio filter (3x3 taps) and the
     complex-mask product, each against its CPU restatement."""

@@ -108,6 +108,27 @@ def test_resunet_onfreq_matches_golden():
                      what="ResUNetOnFreq " + label)
 
 
+def test_udss_matches_golden():
+    gold = load_golden("udss_eval")
+    for label, kw in (("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU"))):
+        net = oracle.UDSS(type_norm="BatchNorm2d", **kw).eval()
+        seeded_fill_(net, seed=61)
+        sf = normal("udss/sf", (2, 4, 257, 16, 2), seed=61)
+        SV = normal("udss/SV", (2, 4, 514), seed=61)
+        ang = uniform("udss/theta", (2,), 0.0, 2 * np.pi, seed=61)
+        theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+        with torch.no_grad():
+            y = net(sf, SV, theta)
+        assert y.dtype == torch.complex64 and tuple(y.shape) == (2, 257, 16)
+        assert_close(torch.view_as_real(y), torch.from_numpy(gold[label]), tol=CPU_TOL, what="UDSS " + label)
+    # the reference's default type_norm is a misspelt name that leaves the norm class unbound
+    try:
+        oracle.UDSS()
+        raise AssertionError("UDSS() should fail like the reference")
+    except KeyError:
+        pass
+
+
 def test_dsunet_matches_golden():
     net = oracle.DSUNet(oracle.dsunet_architecture(45, 8)).eval()
     seeded_fill_(net, seed=41)

@@ -7,6 +7,7 @@
   resunet  ResUNet forward, [32,4,257,501] fp32
   dsunet   DSUNet (UDSS.set_size(45, 8) table) forward, sf [32,8,257,512], SV [32,4,514], theta [32,2]
   helper   DSUNet_helper, wave in -> wave out: [32,4,64000] samples, STFT and inverse STFT included
+  udss     UDSS(type_norm="BatchNorm2d") complex-valued network, sf [32,4,257,512,2], SV [32,4,514], theta [32,2]
 
 One JSON line per workload: audio-seconds/s (4.0 s per utterance), ms per step and the algorithmic
 GFLOP per utterance it implies.  Run it under ``rocprofv3 --kernel-trace --stats`` for the per-kernel
@@ -103,6 +104,38 @@ def main():
             sec = timed(lambda: net(wav, angle, mic), args.steps, args.warmup)
             report("helper", sec, 129.76, "DSUNet_helper wave -> wave: 4-channel 4 s 16 kHz audio, STFT + features + "
                                           "DSUNet + mask + inverse STFT, [B,4,64000] -> [B,64000]")
+            del net, wav, angle, mic
+        if args.only in (None, "udss"):
+            net = unet_amd.UDSS(type_norm="BatchNorm2d")
+            unet_amd.seeded_fill_(net, seed=61)
+            net.eval().to(dev)
+            sf = torch.randn((B, 4, 257, 512, 2), generator=g).to(dev)
+            SV = torch.randn((B, 4, 514), generator=g).to(dev)
+            ang = torch.rand((B,), generator=g) * 2 * math.pi
+            theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1).to(dev)
+            sec = timed(lambda: net(sf, SV, theta), args.steps, args.warmup)
+            report("udss", sec, round(udss_gflop(), 2), "UDSS(type_norm='BatchNorm2d') complex-valued forward, "
+                                                        "sf [B,4,257,512,2], SV [B,4,514], theta [B,2]")
+
+
+def udss_gflop():
+    """Algorithmic GFLOP per utterance of UDSS at F=257, T=512: a complex MAC is 4 real MACs."""
+    from unet_amd.UDSS import udss_table
+    t = udss_table(31, 4)
+    H, W, macs = 257, 512, 0
+    sizes = []
+    for i in range(10):
+        k, s, p = t["enc_kernel_sizes"][i], t["enc_strides"][i], t["enc_paddings"][i]
+        sizes.append((H, W))
+        H, W = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+        macs += 4 * t["enc_channels"][i] * t["enc_channels"][i + 1] * k[0] * k[1] * H * W
+    for i in range(10):
+        k, s = t["dec_kernel_sizes"][i], t["dec_strides"][i]
+        cin = t["dec_channels"][i] + t["enc_channels"][10 - i]
+        macs += 4 * cin * t["dec_channels"][i + 1] * k[0] * k[1] * H * W      # per INPUT pixel of a transposed conv
+        H, W = sizes[9 - i]
+    macs += 4 * t["dec_channels"][-1] * 257 * 512
+    return 2 * macs / 1e9
 
 
 if __name__ == "__main__":

@@ -1,0 +1,401 @@
+"""Device ``UDSS`` -- the complex-valued directional source separation U-Net -- with the reference's
+constructor, ``forward(sf, SV, theta)`` and state_dict keys (UDSS.py:420-683; complex blocks UNet_m.py:88-132,
+:214-225).
+
+A complex convolution is four real convolutions that share their input (UNet_m.py:98-102).  On the device a
+``[B, C, F, T, 2]`` tensor is kept as the real tensor ``[B, 2C, F, T]`` (real parts of all channels, then the
+imaginary parts), and a complex layer is ONE launch of the real convolution kernel with the weight
+
+        | W_re  -W_im |            bias  | b_re - b_im |
+        | W_im   W_re |                  | b_re + b_im |
+
+its two BatchNorms side by side in the epilogue, the activation, the attractor gate (the same factor for both
+parts) and -- for decoders -- the concat with the skip tensor read as a second input.  The stacked weight is
+rebuilt when a parameter changes.  Only the network input and nothing else is re-laid out.
+"""
+
+import torch
+import torch.nn as nn
+
+from .DSUNet import Attractor, AttractEncoder
+from .fused import FusedConv, require_device_tensor
+
+
+def stack_complex(x):
+    """[B, C, F, T, 2] -> [B, 2C, F, T] (real parts first)."""
+    B, C, F, T, _ = x.shape
+    return x.permute(0, 4, 1, 2, 3).reshape(B, 2 * C, F, T).contiguous()
+
+
+def unstack_complex(x):
+    """[B, 2C, F, T] -> [B, C, F, T, 2]."""
+    B, C2, F, T = x.shape
+    return x.reshape(B, 2, C2 // 2, F, T).permute(0, 2, 3, 4, 1).contiguous()
+
+
+class ComplexConv2d(nn.Module):
+    """UNet_m.py:88-102.  ``forward`` takes and returns ``[B, C, F, T, 2]``."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 **kwargs):
+        super().__init__()
+        kw = dict(stride=stride, padding=padding, dilation=dilation, groups=groups, bias=bias, **kwargs)
+        self.conv_re = nn.Conv2d(in_channel, out_channel, kernel_size, **kw)
+        self.conv_im = nn.Conv2d(in_channel, out_channel, kernel_size, **kw)
+        self._layer = None
+
+    def parts(self):
+        return self.conv_re, self.conv_im
+
+    def forward(self, x):
+        require_device_tensor(x, "ComplexConv2d")
+        if self._layer is None:
+            object.__setattr__(self, "_layer", _ComplexLayer(self, None, None))
+        return unstack_complex(self._layer(stack_complex(x)))
+
+
+class ComplexConvTranspose2d(nn.Module):
+    """UNet_m.py:104-132."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, output_padding=0, dilation=1,
+                 groups=1, bias=True, **kwargs):
+        super().__init__()
+        kw = dict(kernel_size=kernel_size, stride=stride, padding=padding, output_padding=output_padding,
+                  groups=groups, bias=bias, dilation=dilation, **kwargs)
+        self.tconv_re = nn.ConvTranspose2d(in_channel, out_channel, **kw)
+        self.tconv_im = nn.ConvTranspose2d(in_channel, out_channel, **kw)
+        self._layer = None
+
+    def parts(self):
+        return self.tconv_re, self.tconv_im
+
+    def forward(self, x):
+        require_device_tensor(x, "ComplexConvTranspose2d")
+        if self._layer is None:
+            object.__setattr__(self, "_layer", _ComplexLayer(self, None, None))
+        return unstack_complex(self._layer(stack_complex(x)))
+
+
+class ComplexBatchNorm2d(nn.Module):
+    """UNet_m.py:214-225: independent BatchNorm2d on the two parts (torch ops when called on its own)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, **kwargs):
+        super().__init__()
+        kw = dict(num_features=num_features, momentum=momentum, affine=affine, eps=eps,
+                  track_running_stats=track_running_stats, **kwargs)
+        self.bn_re = nn.BatchNorm2d(**kw)
+        self.bn_im = nn.BatchNorm2d(**kw)
+
+    def forward(self, x):
+        return torch.stack((self.bn_re(x[..., 0]), self.bn_im(x[..., 1])), dim=-1)
+
+
+class ComplexInstanceNorm2d(nn.Module):
+    """UNet_m.py:227-237."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.in_re = nn.InstanceNorm2d(num_features=num_features)
+        self.in_im = nn.InstanceNorm2d(num_features=num_features)
+
+    def forward(self, x):
+        return torch.stack((self.in_re(x[..., 0]), self.in_im(x[..., 1])), dim=-1)
+
+
+class _ComplexLayer:
+    """One complex conv / transposed conv [+ ComplexBatchNorm2d] [+ activation] on stacked tensors as one
+    fused real-convolution launch.  Owns only caches: the stacked twin modules, rebuilt per input split
+    (channels of x, channels of the skip) and whenever a source parameter changes."""
+
+    def __init__(self, cconv, cbn, act):
+        self.cconv, self.cbn, self.act = cconv, cbn, act
+        self._twins = {}
+        self._key = None
+
+    def _versions(self):
+        ts = []
+        for m in self.cconv.parts():
+            ts += [m.weight, m.bias]
+        if self.cbn is not None:
+            for m in (self.cbn.bn_re, self.cbn.bn_im):
+                ts += [m.weight, m.bias, m.running_mean, m.running_var]
+        return tuple((t._version, t.data_ptr()) if t is not None else None for t in ts)
+
+    def _twin(self, C0, C1):
+        key = self._versions()
+        if key != self._key:
+            self._twins.clear()
+            self._key = key
+        fused = self._twins.get((C0, C1))
+        if fused is not None:
+            return fused
+        re, im = self.cconv.parts()
+        transposed = isinstance(re, nn.ConvTranspose2d)
+        if re.groups != 1:
+            raise NotImplementedError("grouped complex convolutions are not built")
+        ia, oa = (0, 1) if transposed else (1, 0)                       # input / output channel axes of the weight
+        Wr, Wi = re.weight.detach(), im.weight.detach()
+        if Wr.shape[ia] != C0 + C1:
+            raise ValueError("complex layer built for {} input channels, got {} + {}".format(Wr.shape[ia], C0, C1))
+        Wr0, Wr1 = Wr.narrow(ia, 0, C0), Wr.narrow(ia, C0, C1)
+        Wi0, Wi1 = Wi.narrow(ia, 0, C0), Wi.narrow(ia, C0, C1)
+        # stacked input order: re(x), im(x), re(skip), im(skip); stacked output order: re, im
+        to_re = torch.cat([Wr0, -Wi0, Wr1, -Wi1], dim=ia)
+        to_im = torch.cat([Wi0, Wr0, Wi1, Wr1], dim=ia)
+        W = torch.cat([to_re, to_im], dim=oa)
+        K = Wr.shape[oa]
+        kw = dict(kernel_size=re.kernel_size, stride=re.stride, padding=re.padding, dilation=re.dilation)
+        if transposed:
+            twin = nn.ConvTranspose2d(2 * (C0 + C1), 2 * K, output_padding=re.output_padding, **kw)
+        else:
+            twin = nn.Conv2d(2 * (C0 + C1), 2 * K, padding_mode=re.padding_mode, **kw)
+        norm = None
+        with torch.no_grad():
+            twin = twin.to(W.device)
+            twin.weight.copy_(W)
+            br = re.bias.detach() if re.bias is not None else torch.zeros(K, device=W.device)
+            bi = im.bias.detach() if im.bias is not None else torch.zeros(K, device=W.device)
+            twin.bias.copy_(torch.cat([br - bi, br + bi]))
+            if self.cbn is not None:
+                a, b = self.cbn.bn_re, self.cbn.bn_im
+                norm = nn.BatchNorm2d(2 * K, eps=a.eps).to(W.device).eval()
+                norm.weight.copy_(torch.cat([a.weight, b.weight]))
+                norm.bias.copy_(torch.cat([a.bias, b.bias]))
+                norm.running_mean.copy_(torch.cat([a.running_mean, b.running_mean]))
+                norm.running_var.copy_(torch.cat([a.running_var, b.running_var]))
+        fused = FusedConv(twin, norm, self.act)
+        if not fused.fusable():
+            raise NotImplementedError("complex layer: this activation / norm is not one the epilogue has")
+        self._twins[(C0, C1)] = fused
+        return fused
+
+    def __call__(self, x, skip=None, gate=None):
+        """x, skip: stacked [B, 2C, F, T]; gate: [B, K] (applied to both parts)."""
+        C0 = x.shape[1] // 2
+        C1 = 0 if skip is None else skip.shape[1] // 2
+        if gate is not None:
+            gate = torch.cat([gate, gate], dim=1).contiguous()
+        return self._twin(C0, C1)(x, skip, gate=gate)
+
+
+def _norm_cls(type_norm):
+    # UDSS.py:358-361: any other name leaves the class unbound in the reference (UnboundLocalError)
+    if type_norm == "BatchNorm2d":
+        return ComplexBatchNorm2d
+    if type_norm == "InstanceNorm2d":
+        return ComplexInstanceNorm2d
+    raise UnboundLocalError("local variable 'bn' referenced before assignment")
+
+
+def _activation(name):
+    return {"LeakyReLU": lambda: nn.LeakyReLU(inplace=True), "PReLU": nn.PReLU, "SiLU": nn.SiLU}[name]()
+
+
+class _ComplexBlock(nn.Module):
+    def _stacked(self, cconv, x, skip=None, gate=None):
+        if self.training:
+            raise NotImplementedError("{}: train-mode forward is not available in this build; call .eval()"
+                                      .format(type(self).__name__))
+        if not isinstance(self.bn, ComplexBatchNorm2d):
+            raise NotImplementedError("{}: only ComplexBatchNorm2d (eval) is fused".format(type(self).__name__))
+        if self._layer is None:
+            object.__setattr__(self, "_layer", _ComplexLayer(cconv, self.bn, self.relu))
+        return self._layer(x, skip, gate)
+
+
+class Encoder(_ComplexBlock):
+    """Complex conv -> dropout -> complex norm -> activation (UDSS.py:349-386, complex=True)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding=None, complex=True,
+                 padding_mode="zeros", activation="LeakyReLU", dropout=0.0, type_norm="BatchNorm2d"):
+        super().__init__()
+        if not complex:
+            raise NotImplementedError("the real-valued form of this network is unet_amd.DSUNet")
+        if padding is None:
+            padding = [(k - 1) // 2 for k in kernel_size]
+        self.dr = nn.Dropout(dropout)
+        self.conv = ComplexConv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                  padding=padding, padding_mode=padding_mode)
+        self.bn = _norm_cls(type_norm)(out_channels)
+        self.relu = _activation(activation)
+        self._layer = None
+
+    def forward_stacked(self, x, gate=None):
+        return self._stacked(self.conv, x, None, gate)
+
+    def forward(self, x):
+        require_device_tensor(x, "UDSS.Encoder")
+        return unstack_complex(self.forward_stacked(stack_complex(x)))
+
+
+class Decoder(_ComplexBlock):
+    """Complex transposed conv -> complex norm -> activation (UDSS.py:388-418, complex=True)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, output_padding, padding=(0, 0), complex=True,
+                 activation="LeakyReLU", type_norm="BatchNorm2d"):
+        super().__init__()
+        if not complex:
+            raise NotImplementedError("the real-valued form of this network is unet_amd.DSUNet")
+        self.transconv = ComplexConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                                                output_padding=output_padding, padding=padding)
+        self.bn = _norm_cls(type_norm)(out_channels)
+        self.relu = _activation(activation)
+        self._layer = None
+
+    def forward_stacked(self, x, skip=None):
+        return self._stacked(self.transconv, x, skip)
+
+    def forward(self, x):
+        require_device_tensor(x, "UDSS.Decoder")
+        return unstack_complex(self.forward_stacked(stack_complex(x)))
+
+
+class TGRUBlock(_ComplexBlock):
+    """GRU along time over the interleaved (channel, re/im) features of every (batch, frequency) row (torch's
+    device GRU), then complex 1x1 conv + complex BatchNorm + ReLU as one launch (UDSS.py:39-70)."""
+
+    def __init__(self, in_channels, hidden_size, out_channels, skipGRU=False, **kwargs):
+        super().__init__()
+        if skipGRU:
+            raise Exception("Not Implemented")
+        self.GRU = nn.GRU(in_channels * 2, hidden_size * 2, batch_first=True)
+        self.conv = ComplexConv2d(hidden_size, out_channels, kernel_size=1)
+        self.bn = ComplexBatchNorm2d(out_channels)
+        self.hidden_size = hidden_size
+        self.relu = nn.ReLU()
+        self._layer = None
+
+    def forward_stacked(self, x, rnn_state=None):
+        B, C2, F, T = x.shape
+        C = C2 // 2
+        seq = x.reshape(B, 2, C, F, T).permute(0, 3, 4, 2, 1).reshape(B * F, T, C2)      # feature index c*2 + re/im
+        y, _ = self.GRU(seq.float(), rnn_state)
+        H = self.hidden_size
+        y = y.reshape(B, F, T, H, 2).permute(0, 4, 3, 1, 2).reshape(B, 2 * H, F, T).contiguous().to(x.dtype)
+        return self._stacked(self.conv, y)
+
+    def forward(self, x, rnn_state=None):
+        require_device_tensor(x, "UDSS.TGRUBlock")
+        return unstack_complex(self.forward_stacked(stack_complex(x), rnn_state))
+
+
+class CRM(nn.Module):
+    """UDSS.py:91-103."""
+
+    def forward(self, x):
+        m = torch.squeeze(torch.tanh(x), 1)
+        return torch.complex(m[..., 0], m[..., 1])
+
+    def output(self, X, M):
+        return X * M
+
+
+class CM(nn.Module):
+    """UDSS.py:106-116."""
+
+    def forward(self, x):
+        m = torch.squeeze(x, 1)
+        return torch.complex(m[..., 0], m[..., 1])
+
+    def output(self, X, M):
+        return M
+
+
+def udss_table(model_complexity, input_channels):
+    """Layer table of ``UDSS.set_size`` (UDSS.py:582-683)."""
+    mc = model_complexity
+    return dict(
+        enc_channels=[input_channels, mc, mc] + [mc * 2] * 7 + [128],
+        enc_kernel_sizes=[(7, 1), (1, 7), (7, 5), (7, 5)] + [(5, 3)] * 6,
+        enc_strides=[(1, 1), (1, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (2, 1)],
+        enc_paddings=[(3, 0), (0, 3), (3, 2), (3, 2)] + [(2, 1)] * 6,
+        dec_channels=[0] + [mc * 2] * 11,
+        dec_kernel_sizes=[(5, 3)] * 6 + [(7, 5), (7, 5), (1, 7), (7, 1)],
+        dec_strides=[(2, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (2, 1), (2, 2), (1, 1), (1, 1)],
+        dec_paddings=[(2, 1)] * 6 + [(3, 2), (3, 2), (0, 3), (3, 0)],
+        dec_output_paddings=[(0, 0), (0, 1)] * 4 + [(0, 0), (0, 0)])
+
+
+class UDSS(nn.Module):
+    """``complex=True``, ``type_encoder="Complex"``, bottleneck "None" or "TGRU", masks "CRM" / "CM".  As in the
+    reference the default ``type_norm`` ("BatcNorm2d", sic) fails at construction; pass "BatchNorm2d"."""
+
+    def __init__(self, input_channels=4, n_fft=512, complex=True, model_complexity=45, bottleneck="None",
+                 padding_mode="zeros", type_encoder="Complex", type_masking="CRM", activation="LeakyReLU",
+                 dropout=0.0, type_norm="BatcNorm2d"):
+        super().__init__()
+        if not complex:
+            raise NotImplementedError("the real-valued form of this network is unet_amd.DSUNet")
+        self.bottleneck = bottleneck
+        self.complex = complex
+        self.n_channel = input_channels
+        model_complexity = int(model_complexity // 1.414)
+        print("UDSS::complexity {}".format(model_complexity))
+        self.set_size(model_complexity=model_complexity, input_channels=input_channels, model_depth=20)
+        L = self.model_length = 10
+        self.dropout = dropout
+        if type_encoder != "Complex":
+            raise Exception("Not Implemented")          # ComplexDepthSeparable fails in the reference's constructor
+        encs = [Encoder(self.enc_channels[i], self.enc_channels[i + 1], kernel_size=self.enc_kernel_sizes[i],
+                        stride=self.enc_strides[i], padding=self.enc_paddings[i], padding_mode=padding_mode,
+                        dropout=dropout, activation=activation, type_norm=type_norm) for i in range(L)]
+        for i, m in enumerate(encs):
+            self.add_module("encoder{}".format(i), m)
+        decs = [Decoder(self.dec_channels[i] + self.enc_channels[L - i], self.dec_channels[i + 1],
+                        kernel_size=self.dec_kernel_sizes[i], stride=self.dec_strides[i],
+                        padding=self.dec_paddings[i], output_padding=self.dec_output_paddings[i],
+                        activation=activation) for i in range(L)]
+        for i, m in enumerate(decs):
+            self.add_module("decoder{}".format(i), m)
+        if bottleneck == "TGRU":
+            self.BTN = TGRUBlock(128, 256, 128)
+        elif bottleneck in ("cRNN", "FTGRU", "RNN_AS", "AATT"):
+            raise NotImplementedError("UDSS: bottleneck {} is not built".format(bottleneck))
+        else:
+            self.BTN = nn.Identity()
+        self.Attractor = Attractor(n_ch=4, n_fft=n_fft)
+        self.attractEncoders = [AttractEncoder(n_ch=self.enc_channels[i + 1]) for i in range(L)]
+        for i, m in enumerate(self.attractEncoders):
+            self.add_module("attractEncoder_{}".format(i), m)
+        self.add_module("linear", ComplexConv2d(self.dec_channels[-1], 1, 1))
+        self.padding_mode = padding_mode
+        if type_masking == "CRM":
+            self.mask = CRM()
+        elif type_masking == "CM":
+            self.mask = CM()
+        else:
+            raise Exception("Not Implemented")
+        self.dr = nn.Dropout(self.dropout)
+        self.decoders = nn.ModuleList(decs)
+        self.encoders = nn.ModuleList(encs)
+        self.attractors = nn.ModuleList(self.attractEncoders)
+        self._head = None
+
+    def set_size(self, model_complexity, model_depth=20, input_channels=1):
+        for k, v in udss_table(model_complexity, input_channels).items():
+            setattr(self, k, v)
+
+    def forward(self, sf, SV, theta):
+        require_device_tensor(sf, "UDSS")
+        if self.training:
+            raise NotImplementedError("UDSS: train-mode forward is not available in this build; call .eval()")
+        if sf.dim() != 5 or sf.shape[-1] != 2:
+            raise ValueError("UDSS: sf must be [B, C, F, T, 2]")
+        attract = self.Attractor(SV.float(), theta.float())
+        L = self.model_length
+        x = stack_complex(sf)
+        skips = []
+        for i, enc in enumerate(self.encoders):
+            skips.append(x)
+            x = enc.forward_stacked(x, self.attractEncoders[i](attract).float().contiguous())
+        p = self.BTN.forward_stacked(x) if isinstance(self.BTN, TGRUBlock) else x
+        for i, dec in enumerate(self.decoders):
+            p = dec.forward_stacked(p, None if i == 0 else skips[L - i])
+        if self._head is None:
+            act = nn.Tanh() if isinstance(self.mask, CRM) else None
+            object.__setattr__(self, "_head", _ComplexLayer(self.linear, None, act))
+        m = self._head(p).float()                                       # [B, 2, F, T]: re, im (squashed for CRM)
+        return torch.complex(m[:, 0, ...], m[:, 1, ...])
+
+    def masking(self, X, M):
+        return self.mask.output(X, M)
