@@ -272,6 +272,98 @@ class ResUNetOnFreq(nn.Module):
         return mask * feature[:, :2]
 
 
+class LSTMBlock(nn.Module):
+    """[B,C,F',T] -> [B,T,C*F'] -> projected LSTM -> back.  Restates UNet_m.py:587-610."""
+
+    def __init__(self, n_dim, n_hidden, n_layer=3, proj_size=None, dropout=0.2):
+        super().__init__()
+        if proj_size is None:
+            proj_size = n_dim
+        self.rnn = nn.LSTM(n_dim, n_hidden, n_layer, batch_first=True, proj_size=proj_size, dropout=dropout)
+
+    def forward(self, x):
+        shape = x.shape
+        seq = torch.permute(torch.reshape(x, (shape[0], shape[1] * shape[2], shape[3])), (0, 2, 1))
+        y = torch.permute(self.rnn(seq)[0], (0, 2, 1))
+        return torch.reshape(y, tuple(shape))
+
+
+class ResUNetOnFreq2(nn.Module):
+    """ResUNetOnFreq cut after its 30-channel blocks: six encoders down to 7 frequency rows, an LSTM over the
+    flattened (channel, frequency) features, six decoders, one-channel mask.  Restates ResUNet.py:394-591 for
+    ``multi_scale=False`` and the LSTM bottleneck.
+
+    The reference indexes the bottleneck's output tensor with ``[0]`` (ResUNet.py:565, a leftover of
+    ``nn.LSTM``'s tuple): the batch axis is dropped, so the FIRST sample's bottleneck output is broadcast to
+    every sample of the batch by the following add.  That behaviour is restated as it is."""
+
+    def __init__(self, c_in=1, c_out=1, n_fft=512, device="cuda:0", print_shape=False, n_block=5,
+                 activation="Softplus", bottleneck="LSTM", Softplus_thr=20, norm="BatchNorm2d", dropout=0.0,
+                 activation_layer="PReLU", multi_scale=False):
+        super().__init__()
+        n_hfft = int(n_fft / 2 + 1)
+        self.print_shape = print_shape
+        self.activation = activation
+        self.multi_scale = multi_scale
+        self.F = n_hfft
+        W = 30
+        if n_block < 2:
+            raise Exception("ERROR::ResUnetOnFreq : n_block({}) < 2".format(n_block))
+        if multi_scale:
+            raise NotImplementedError("multi_scale=True is not restated")
+        if bottleneck == "FTGRU":
+            raise NotImplementedError("bottleneck FTGRU is not restated")
+        kw = dict(activation=activation_layer, norm=norm)
+        self.layer_input = nn.Sequential(Encoder(c_in, W, (1, 3), 1, (0, 1), 1), nn.LayerNorm(n_hfft))
+        self.encoders = [ResBlock(W)] + [nn.Sequential(Encoder(W, W, (3, 1), (2, 1), (0, 0), **kw), ResBlock(30))
+                                         for _ in range(n_block)]
+        for i, m in enumerate(self.encoders):
+            self.add_module("enc_{}".format(i), m)
+
+        def up(kh):
+            return nn.Sequential(ResBlock(W), Decoder(W, W, (kh, 1), (2, 1), (1, 0), output_padding=(1, 0), **kw))
+
+        self.decoders = [up(4) for _ in range(n_block - 2)] + [up(5), up(4), ResBlock(W)]
+        for i, m in enumerate(self.decoders):
+            self.add_module("dec_{}".format(i), m)
+        self.len_model = len(self.encoders)
+        self.res_paths = [Encoder(W, W, 1, 1, 0, 1, activation=activation_layer) for _ in range(n_block + 1)]
+        for i, m in enumerate(self.res_paths):
+            self.add_module("res_path_{}".format(i), m)
+        self.bottleneck = LSTMBlock(210, 300, n_layer=3, dropout=dropout)
+        self.out_layer = nn.ConvTranspose2d(W, c_out, (3, 1), stride=1, padding=(1, 0), dilation=1,
+                                            output_padding=(0, 0))
+        if activation == "Softplus":
+            self.activation_mask = nn.Softplus(threshold=Softplus_thr)
+        elif activation == "Sigmoid":
+            self.activation_mask = nn.Sigmoid()
+        elif activation == "Tanh":
+            self.activation_mask = nn.Tanh()
+        elif activation == "Identity":
+            self.activation_mask = nn.Identity()
+        elif activation == "MEA":
+            raise NotImplementedError("the MEA head is not restated")
+        else:
+            self.activation_mask = nn.Softplus()
+
+    def forward(self, input):
+        feat = self.layer_input(torch.permute(input, (0, 1, 3, 2)))
+        x = torch.permute(feat, (0, 1, 3, 2))
+        res = []
+        for enc in self.encoders:
+            x = enc(x)
+            res.append(x)
+        y = self.bottleneck(x)[0]                    # [C, F', T]: sample 0 only (see the class docstring)
+        for i, rp in enumerate(self.res_paths):
+            res[i] = rp(res[i])
+        for i, dec in enumerate(self.decoders):
+            y = dec(torch.add(y, res[-1 - i]))
+        return self.activation_mask(self.out_layer(y))
+
+    def output(self, mask, feature):
+        return mask * feature[:, :2]
+
+
 class DSUNet(nn.Module):
     """Directional-separating U-Net built from an external architecture dict
     (keys ``encoder.enc{1..L}`` / ``decoder.dec{L..1}``); each encoder output is

@@ -229,6 +229,22 @@ def main():
         if out is not None:
             save("resunet_onfreq_eval_" + label, out=y_ref.numpy())
 
+    print("ResUNetOnFreq2 as shipped (one input channel, LSTM bottleneck, Softplus and Tanh masks), B=2 F=257 T=16")
+    for label, kw in (("softplus", {}), ("tanh", dict(activation="Tanh", c_in=2))):
+        ref = R_res.ResUNetOnFreq2(**kw)
+        seeded_fill_(ref, seed=34)
+        mine = oracle.ResUNetOnFreq2(**kw)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+        x = normal("resunet_onfreq2/x_" + label, (2, kw.get("c_in", 1), 257, 16), seed=34)
+        ref.eval(), mine.eval()
+        with torch.no_grad():
+            y_ref, y_mine = ref(x), mine(x)
+        require_equal(y_ref, y_mine, "ResUNetOnFreq2 eval " + label)
+        assert tuple(y_ref.shape) == (2, 1, 257, 16)
+        if out is not None:
+            save("resunet_onfreq2_eval_" + label, out=y_ref.numpy())
+
     print("UNet_m.ResBlock(16), B=2 F=9 T=40 (eval and train)")
     ref = R_m.ResBlock(16)
     seeded_fill_(ref, seed=32)
@@ -361,15 +377,14 @@ def main():
         facts["ResBlock_GELU"] = "ok"
     except Exception as e:  # noqa: BLE001
         facts["ResBlock_GELU"] = type(e).__name__
-    # ResUNetOnFreq2 does not run as shipped, whichever bottleneck it is built with
-    for bn_kind in ("LSTM", "GRU", "None"):
-        try:
-            net = R_res.ResUNetOnFreq2(bottleneck=bn_kind).eval()
-            with torch.no_grad():
-                net(torch.zeros(1, 1, 257, 16))
-            facts["ResUNetOnFreq2_" + bn_kind] = "ok"
-        except Exception as e:  # noqa: BLE001
-            facts["ResUNetOnFreq2_" + bn_kind] = type(e).__name__
+    # ResUNetOnFreq2's FTGRU bottleneck does not run as shipped
+    try:
+        net = R_res.ResUNetOnFreq2(bottleneck="FTGRU").eval()
+        with torch.no_grad():
+            net(torch.zeros(1, 1, 257, 16))
+        facts["ResUNetOnFreq2_FTGRU"] = "ok"
+    except Exception as e:  # noqa: BLE001
+        facts["ResUNetOnFreq2_FTGRU"] = type(e).__name__
     facts["UDSS_default_type_norm"] = udss_default
     print("  ", facts)
     assert facts["UNet_without_global"] == "NameError" and facts["UNet10"] == "TypeError"

@@ -132,6 +132,27 @@ def test_resunet_onfreq_matches_golden_and_oracle(device):
         assert_close(dev.output(got, x.to(device)), ref.output(want, x), what="ResUNetOnFreq.output")
 
 
+def test_resunet_onfreq2_matches_golden_and_oracle(device):
+    """ResUNetOnFreq2, including the reference's behaviour of feeding sample 0's bottleneck output to the
+    whole batch (the two samples of the input differ, so a per-sample bottleneck would not match)."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    for label, kw in (("softplus", {}), ("tanh", dict(activation="Tanh", c_in=2))):
+        ref = oracle.ResUNetOnFreq2(**kw).eval()
+        unet_amd.seeded_fill_(ref, seed=34)
+        dev = unet_amd.ResUNetOnFreq2(**kw)
+        dev.load_state_dict(ref.state_dict(), strict=True)
+        x = normal("resunet_onfreq2/x_" + label, (2, kw.get("c_in", 1), 257, 16), seed=34)
+        with torch.no_grad():
+            want = ref(x)
+            got = dev.eval().to(device)(x.to(device))
+        assert tuple(got.shape) == (2, 1, 257, 16)
+        assert_close(got, want, what="ResUNetOnFreq2 {} HIP vs oracle".format(label))
+        assert_close(got, torch.from_numpy(load_golden("resunet_onfreq2_eval_" + label)["out"]),
+                     what="ResUNetOnFreq2 {} HIP vs golden".format(label))
+
+
 @pytest.mark.parametrize("label,kw", [("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU"))])
 def test_udss_matches_golden_and_oracle(device, label, kw):
     """The complex-valued family: every complex conv / transposed conv (+ both BatchNorms, activation, gate,

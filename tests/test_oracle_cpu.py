@@ -108,6 +108,17 @@ def test_resunet_onfreq_matches_golden():
                      what="ResUNetOnFreq " + label)
 
 
+def test_resunet_onfreq2_matches_golden():
+    for label, kw in (("softplus", {}), ("tanh", dict(activation="Tanh", c_in=2))):
+        net = oracle.ResUNetOnFreq2(**kw).eval()
+        seeded_fill_(net, seed=34)
+        x = normal("resunet_onfreq2/x_" + label, (2, kw.get("c_in", 1), 257, 16), seed=34)
+        with torch.no_grad():
+            y = net(x)
+        assert_close(y, torch.from_numpy(load_golden("resunet_onfreq2_eval_" + label)["out"]), tol=CPU_TOL,
+                     what="ResUNetOnFreq2 " + label)
+
+
 def test_udss_matches_golden():
     gold = load_golden("udss_eval")
     for label, kw in (("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU"))):

@@ -22,9 +22,9 @@ from .lstm import lstm_forward, supported as lstm_supported
 from .ops import layernorm_f, tanh_mask_mul
 
 
-def _trunk(net, x):
+def _trunk(net, x, bottleneck=None):
     """Encoders, projected-LSTM bottleneck, 1x1 res-paths and the additive-skip decoders shared by
-    ResUNet and ResUNetOnFreq (ResUNet.py:176-215 == ResUNet.py:344-381)."""
+    ResUNet, ResUNetOnFreq and ResUNetOnFreq2 (ResUNet.py:176-215 == :344-381 == :543-580)."""
     res = []
     for i, enc in enumerate(net.encoders):
         x = enc(x)
@@ -32,14 +32,17 @@ def _trunk(net, x):
             print("x_{} : {}".format(i, x.shape))
         res.append(x)
 
-    # [B,C,1,T] -> [B,T,C] -> projected LSTM -> [B,C,1,T]: one persistent launch per layer for the
-    # recurrence (unet_amd/lstm.py); an LSTM of another shape runs torch's device implementation
-    seq = x.reshape(x.shape[0], x.shape[1], x.shape[3]).permute(0, 2, 1)
-    if lstm_supported(net.bottleneck):
-        seq = lstm_forward(net.bottleneck, seq.float(), net._lstm_cache).to(x.dtype)
+    if bottleneck is not None:
+        y = bottleneck(x)
     else:
-        seq = net.bottleneck(seq)[0]
-    y = seq.permute(0, 2, 1).reshape(x.shape[0], x.shape[1], 1, x.shape[3]).contiguous()
+        # [B,C,1,T] -> [B,T,C] -> projected LSTM -> [B,C,1,T]: one persistent launch per layer for the
+        # recurrence (unet_amd/lstm.py); an LSTM of another shape runs torch's device implementation
+        seq = x.reshape(x.shape[0], x.shape[1], x.shape[3]).permute(0, 2, 1)
+        if lstm_supported(net.bottleneck):
+            seq = lstm_forward(net.bottleneck, seq.float(), net._lstm_cache).to(x.dtype)
+        else:
+            seq = net.bottleneck(seq)[0]
+        y = seq.permute(0, 2, 1).reshape(x.shape[0], x.shape[1], 1, x.shape[3]).contiguous()
 
     for i, rp in enumerate(net.res_paths):
         res[i] = rp(res[i])
@@ -199,6 +202,109 @@ class ResUNetOnFreq(nn.Module):
                                               fusable))
         head, fused_act = self._out
         # the mask comes out of a thin layer: keep it in fp32 whatever the storage type of the trunk
+        m = head(y.float() if y.dtype != torch.float32 else y)
+        if not fused_act:
+            m = self.activation_mask(m)
+        return m.to(y.dtype)
+
+    def output(self, mask, feature):
+        return mask * feature[:, :2]
+
+
+class LSTMBlock(nn.Module):
+    """[B,C,F',T] -> [B,T,C*F'] -> projected LSTM -> back (UNet_m.py:587-610); torch's device LSTM."""
+
+    def __init__(self, n_dim, n_hidden, n_layer=3, proj_size=None, dropout=0.2):
+        super().__init__()
+        if proj_size is None:
+            proj_size = n_dim
+        self.rnn = nn.LSTM(n_dim, n_hidden, n_layer, batch_first=True, proj_size=proj_size, dropout=dropout)
+
+    def forward(self, x):
+        require_device_tensor(x, "LSTMBlock")
+        B, C, F, T = x.shape
+        seq = x.reshape(B, C * F, T).permute(0, 2, 1)
+        y = self.rnn(seq.float())[0].to(x.dtype)
+        return y.permute(0, 2, 1).reshape(B, C, F, T).contiguous()
+
+
+class ResUNetOnFreq2(nn.Module):
+    """Device ``ResUNetOnFreq2`` (ResUNet.py:394-591) for ``multi_scale=False`` and the LSTM bottleneck:
+    ResUNetOnFreq's 30-channel blocks only, an LSTM over the flattened (channel, frequency) features at 7
+    frequency rows, one-channel mask.
+
+    The reference indexes the bottleneck's output TENSOR with ``[0]`` (ResUNet.py:565), which drops the batch
+    axis: the first sample's bottleneck output is what every sample of the batch receives through the
+    following add.  The device path reproduces that."""
+
+    def __init__(self, c_in=1, c_out=1, n_fft=512, device="cuda:0", print_shape=False, n_block=5,
+                 activation="Softplus", bottleneck="LSTM", Softplus_thr=20, norm="BatchNorm2d", dropout=0.0,
+                 activation_layer="PReLU", multi_scale=False):
+        super().__init__()
+        n_hfft = int(n_fft / 2 + 1)
+        self.print_shape = print_shape
+        self.activation = activation
+        self.multi_scale = multi_scale
+        self.F = n_hfft
+        W = 30
+        if n_block < 2:
+            raise Exception("ERROR::ResUnetOnFreq : n_block({}) < 2".format(n_block))
+        if multi_scale:
+            raise NotImplementedError("ResUNetOnFreq2: multi_scale=True is not built")
+        if bottleneck == "FTGRU":
+            raise NotImplementedError("ResUNetOnFreq2: the FTGRU bottleneck fails in the reference's constructor")
+        kw = dict(activation=activation_layer, norm=norm)
+        self.layer_input = nn.Sequential(Encoder(c_in, W, (1, 3), 1, (0, 1), 1), nn.LayerNorm(n_hfft))
+        self.encoders = [ResBlock(W)] + [nn.Sequential(Encoder(W, W, (3, 1), (2, 1), (0, 0), **kw), ResBlock(30))
+                                         for _ in range(n_block)]
+        for i, m in enumerate(self.encoders):
+            self.add_module("enc_{}".format(i), m)
+
+        def up(kh):
+            return nn.Sequential(ResBlock(W), Decoder(W, W, (kh, 1), (2, 1), (1, 0), output_padding=(1, 0), **kw))
+
+        self.decoders = [up(4) for _ in range(n_block - 2)] + [up(5), up(4), ResBlock(W)]
+        for i, m in enumerate(self.decoders):
+            self.add_module("dec_{}".format(i), m)
+        self.len_model = len(self.encoders)
+        self.res_paths = [Encoder(W, W, 1, 1, 0, 1, activation=activation_layer) for _ in range(n_block + 1)]
+        for i, m in enumerate(self.res_paths):
+            self.add_module("res_path_{}".format(i), m)
+        self.bottleneck = LSTMBlock(210, 300, n_layer=3, dropout=dropout)
+        self.out_layer = nn.ConvTranspose2d(W, c_out, (3, 1), stride=1, padding=(1, 0), dilation=1,
+                                            output_padding=(0, 0))
+        if activation == "Softplus":
+            self.activation_mask = nn.Softplus(threshold=Softplus_thr)
+        elif activation == "Sigmoid":
+            self.activation_mask = nn.Sigmoid()
+        elif activation == "Tanh":
+            self.activation_mask = nn.Tanh()
+        elif activation == "Identity":
+            self.activation_mask = nn.Identity()
+        elif activation == "MEA":
+            raise NotImplementedError("ResUNetOnFreq2: the MEA head is not built")
+        else:
+            self.activation_mask = nn.Softplus()
+        self._in = self._out = None
+
+    def _first_sample_bottleneck(self, x):
+        y = self.bottleneck(x)[0]                                    # [C, F', T]
+        return y.unsqueeze(0).expand(x.shape[0], -1, -1, -1).contiguous()
+
+    def forward(self, input):
+        require_device_tensor(input, "ResUNetOnFreq2")
+        if self.training:
+            raise NotImplementedError("ResUNetOnFreq2: train-mode forward is not available in this build; call .eval()")
+        B, _, F, T = input.shape
+        x = torch.empty((B, 30, F, T), dtype=input.dtype, device=input.device)
+        ResUNet._input_branch(self, self.layer_input, "_in", input.contiguous(), x, 0)
+        y = _trunk(self, x, self._first_sample_bottleneck)
+        if self._out is None:
+            from .fused import activation_code
+            fusable = activation_code(self.activation_mask) is not None
+            object.__setattr__(self, "_out", (FusedConv(self.out_layer, None, self.activation_mask if fusable else None),
+                                              fusable))
+        head, fused_act = self._out
         m = head(y.float() if y.dtype != torch.float32 else y)
         if not fused_act:
             m = self.activation_mask(m)
