@@ -209,7 +209,7 @@ def _bf16_bits(x):
 
 def test_b16_weight_image_layout():
     """unetmi_conv2d_b16_pack_weights (a host function): the image is
-    [phase][16-channel group][tap row][column phase][tap col][half][32-channel tile][k half][row][8 k],
+    [phase][16-channel group][weight half][tap row][column phase][tap col][32-channel tile][k half][row][8 k],
     channels of the two concat sources padded separately to multiples of 16, transposed layers split into
     stride phases with the taps of each phase only."""
     import torch
@@ -221,7 +221,7 @@ def test_b16_weight_image_layout():
     img = pack_b16_weights(torch.from_numpy(w), C0, C1, [K, kh, kw, 1, 1, 1, 0, 1, 1, 0, 0], 0, halves=2).numpy().view(np.uint16)
     G0, G1, MT = 2, 1, 2
     assert img.size == (G0 + G1) * kh * kw * 2 * MT * 2 * 32 * 8
-    img = img.reshape(G0 + G1, kh, kw, 2, MT, 2, 32, 8)
+    img = img.reshape(G0 + G1, 2, kh, kw, MT, 2, 32, 8)          # [group][weight half][tap row][tap col][tile][k half][row][k]
     hi = _bf16_bits(w)
     lo = _bf16_bits(w - (hi.astype(np.uint32) << 16).view(np.float32))
     for g, hf, k, co in [(0, 0, 0, 0), (0, 1, 7, 39), (1, 0, 3, 17), (1, 0, 4, 5), (2, 0, 5, 33), (2, 1, 3, 8), (2, 1, 4, 8), (0, 0, 1, 40)]:
@@ -229,7 +229,7 @@ def test_b16_weight_image_layout():
         ci = (cl if cl < C0 else -1) if g < G0 else (C0 + cl if cl < C1 else -1)
         for th in range(kh):
             for tw in range(kw):
-                got = img[g, th, tw, :, co // 32, hf, co % 32, k]
+                got = img[g, :, th, tw, co // 32, hf, co % 32, k]
                 if ci < 0 or co >= K:
                     assert got[0] == 0 and got[1] == 0
                 else:

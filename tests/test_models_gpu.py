@@ -182,6 +182,41 @@ def test_udss_matches_golden_and_oracle(device, label, kw):
     assert_close(dev.masking(X.to(device), got), ref.masking(X, want), what="UDSS masking")
 
 
+def test_udss_bf16(device):
+    """UDSS on a bfloat16 input.  Default: widened to fp32, i.e. the fp32 bar.  Opt-in (``bf16_matrix``): bfloat16
+    operands on the blocked layout, the 256-real-channel bottleneck encoder split over two launches.  For that
+    path only the relative L2 error is held to 1e-2: bfloat16 activations through this network's 21 complex layers
+    leave single points up to 6e-2 of the output range off, with exact weights too (printed)."""
+    import numpy as np
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.UDSS(type_norm="BatchNorm2d").eval()
+    unet_amd.seeded_fill_(ref, seed=61)
+    dev = unet_amd.UDSS(type_norm="BatchNorm2d")
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    sf = normal("udss/sfbf", (2, 4, 257, 32, 2), seed=65).to(torch.bfloat16)
+    SV = normal("udss/SV", (2, 4, 514), seed=61)
+    ang = uniform("udss/theta", (2,), 0.0, 2 * np.pi, seed=61)
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    with torch.no_grad():
+        want = ref(sf.float(), SV, theta)
+        assert dev.bf16_matrix is False
+        got = dev(sf.to(device), SV.to(device), theta.to(device))
+        assert got.dtype == torch.complex64
+        assert_close(got, want, what="UDSS bf16 input widened to fp32")
+        dev.bf16_matrix = True
+        for halves in (2, 1):
+            dev.bf16_weight_halves = halves
+            got = dev(sf.to(device), SV.to(device), theta.to(device))
+            g, w = torch.view_as_real(got.cpu()), torch.view_as_real(want)
+            l2 = ((g - w).norm() / w.norm()).item()
+            print("UDSS bf16 operands, {} weight half(s): relative L2 {:.3e}, max-norm {:.3e}".format(
+                halves, l2, ((g - w).abs().max() / w.abs().max()).item()))
+            assert l2 <= (1e-2 if halves == 2 else 1.5e-2), "UDSS bf16 operands: relative L2 {:.3e}".format(l2)
+
+
 def test_udss_blocks_and_errors(device):
     """The complex blocks on their own ([B,C,F,T,2] in and out) and the constructor's error behaviour."""
     import oracle.udss as O

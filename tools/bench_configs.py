@@ -107,15 +107,16 @@ def main():
             del net, wav, angle, mic
         if args.only in (None, "udss"):
             net = unet_amd.UDSS(type_norm="BatchNorm2d")
+            net.bf16_matrix = True                       # with --dtype bf16: bfloat16 operands (opt-in for this network)
             unet_amd.seeded_fill_(net, seed=61)
             net.eval().to(dev)
-            sf = torch.randn((B, 4, 257, 512, 2), generator=g).to(dev)
+            sf = torch.randn((B, 4, 257, 512, 2), generator=g).to(dev).to(act)
             SV = torch.randn((B, 4, 514), generator=g).to(dev)
             ang = torch.rand((B,), generator=g) * 2 * math.pi
             theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1).to(dev)
             sec = timed(lambda: net(sf, SV, theta), args.steps, args.warmup)
             report("udss", sec, round(udss_gflop(), 2), "UDSS(type_norm='BatchNorm2d') complex-valued forward, "
-                                                        "sf [B,4,257,512,2], SV [B,4,514], theta [B,2]")
+                                                        "sf [B,4,257,512,2], SV [B,4,514], theta [B,2]", args.dtype)
 
 
 def udss_gflop():

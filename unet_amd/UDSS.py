@@ -166,8 +166,50 @@ class _ComplexLayer:
         fused = FusedConv(twin, norm, self.act)
         if not fused.fusable():
             raise NotImplementedError("complex layer: this activation / norm is not one the epilogue has")
+        fused.twin_modules = (twin, norm)             # the bfloat16-operand path builds its images from the same twin
         self._twins[(C0, C1)] = fused
         return fused
+
+    def blocked(self, x, skip=None, gate=None, nchw_out=False, halves=1):
+        """The same layer on channel-blocked bfloat16 tensors (unet_amd/blocked.py).  The bf16 kernel takes at
+        most 128 output channels per launch; a wider layer (the 128-complex-channel bottleneck encoder) runs as
+        two launches, real outputs and imaginary outputs, whose blocks are then joined."""
+        from .blocked import BlockedConv, BlockedTensor
+        C0 = x.C // 2
+        C1 = 0 if skip is None else skip.C // 2
+        fused = self._twin(C0, C1)
+        layers = getattr(fused, "blocked_layers", None)
+        if layers is None or fused.blocked_halves != halves:
+            twin, norm = fused.twin_modules
+            K2 = twin.out_channels
+            if K2 <= 128:
+                layers = [BlockedConv(twin, norm, self.act, halves=halves, nchw_out=nchw_out)]
+            else:
+                transposed = isinstance(twin, nn.ConvTranspose2d)
+                K = K2 // 2
+                if K > 128 or K % 16 != 0:
+                    raise NotImplementedError("complex layer with {} outputs on the bfloat16 path".format(K))
+                layers = []
+                for h in range(2):                         # real outputs, imaginary outputs
+                    kw = dict(kernel_size=twin.kernel_size, stride=twin.stride, padding=twin.padding, dilation=twin.dilation)
+                    part = (nn.ConvTranspose2d(twin.in_channels, K, output_padding=twin.output_padding, **kw) if transposed
+                            else nn.Conv2d(twin.in_channels, K, **kw)).to(twin.weight.device)
+                    pn = None
+                    with torch.no_grad():
+                        part.weight.copy_(twin.weight.narrow(1 if transposed else 0, h * K, K))
+                        part.bias.copy_(twin.bias[h * K:(h + 1) * K])
+                        if norm is not None:
+                            pn = nn.BatchNorm2d(K, eps=norm.eps).to(twin.weight.device).eval()
+                            for name in ("weight", "bias", "running_mean", "running_var"):
+                                getattr(pn, name).copy_(getattr(norm, name)[h * K:(h + 1) * K])
+                    layers.append(BlockedConv(part, pn, self.act, halves=halves, nchw_out=nchw_out))
+            fused.blocked_layers = layers
+            fused.blocked_halves = halves
+        if len(layers) == 1:
+            g = None if gate is None else torch.cat([gate, gate], dim=1).contiguous()
+            return layers[0](x, skip, g)
+        outs = [l(x, skip, None if gate is None else gate.contiguous()) for l in layers]
+        return BlockedTensor(torch.cat([o.data for o in outs], dim=1), sum(o.C for o in outs))
 
     def __call__(self, x, skip=None, gate=None):
         """x, skip: stacked [B, 2C, F, T]; gate: [B, K] (applied to both parts)."""
@@ -370,6 +412,13 @@ class UDSS(nn.Module):
         self.encoders = nn.ModuleList(encs)
         self.attractors = nn.ModuleList(self.attractEncoders)
         self._head = None
+        # A bfloat16 input is widened to fp32 by default.  True: bfloat16 operands on the matrix cores over the
+        # channel-blocked layout (unet_amd/blocked.py), 4-6x faster -- opt-in, because bfloat16 activations between
+        # the 21 complex layers of this network cost 7e-3 relative L2 error and up to 6e-2 of the output range at
+        # single points, whatever the weights' precision (measured against the fp32 CPU forward).
+        self.bf16_matrix = False
+        # 2: each weight goes in as bfloat16 + its rounding remainder (two MFMAs); with 1 the L2 error is 1.04e-2
+        self.bf16_weight_halves = 2
 
     def set_size(self, model_complexity, model_depth=20, input_channels=1):
         for k, v in udss_table(model_complexity, input_channels).items():
@@ -383,6 +432,12 @@ class UDSS(nn.Module):
             raise ValueError("UDSS: sf must be [B, C, F, T, 2]")
         attract = self.Attractor(SV.float(), theta.float())
         L = self.model_length
+        if sf.dtype == torch.bfloat16:
+            if self.bf16_matrix and isinstance(self.BTN, nn.Identity) and all(
+                    isinstance(m.bn, ComplexBatchNorm2d) and isinstance(m.relu, (nn.LeakyReLU, nn.PReLU))
+                    for m in list(self.encoders) + list(self.decoders)):
+                return self._forward_blocked(sf, attract)
+            sf = sf.float()
         x = stack_complex(sf)
         skips = []
         for i, enc in enumerate(self.encoders):
@@ -395,6 +450,31 @@ class UDSS(nn.Module):
             act = nn.Tanh() if isinstance(self.mask, CRM) else None
             object.__setattr__(self, "_head", _ComplexLayer(self.linear, None, act))
         m = self._head(p).float()                                       # [B, 2, F, T]: re, im (squashed for CRM)
+        return torch.complex(m[:, 0, ...], m[:, 1, ...])
+
+    def _forward_blocked(self, sf, attract):
+        from .blocked import BlockedTensor
+        L = self.model_length
+        x = BlockedTensor.from_nchw(stack_complex(sf))
+        skips = []
+        for i, enc in enumerate(self.encoders):
+            skips.append(x)
+            if enc._layer is None:
+                object.__setattr__(enc, "_layer", _ComplexLayer(enc.conv, enc.bn, enc.relu))
+            x = enc._layer.blocked(x, None, self.attractEncoders[i](attract).float(), halves=self.bf16_weight_halves)
+        for i, dec in enumerate(self.decoders):
+            if dec._layer is None:
+                object.__setattr__(dec, "_layer", _ComplexLayer(dec.transconv, dec.bn, dec.relu))
+            x = dec._layer.blocked(x, None if i == 0 else skips[L - i], halves=self.bf16_weight_halves)
+        if self._head is None:
+            act = nn.Tanh() if isinstance(self.mask, CRM) else None
+            object.__setattr__(self, "_head", _ComplexLayer(self.linear, None, act))
+        head = self._head
+        if getattr(head, "_plain", None) is None:
+            head._plain = _ComplexLayer(self.linear, None, None)
+        m = head._plain.blocked(x, nchw_out=True, halves=self.bf16_weight_halves)     # fp32 [B, 2, F, T]
+        if isinstance(self.mask, CRM):
+            m = torch.tanh(m)
         return torch.complex(m[:, 0, ...], m[:, 1, ...])
 
     def masking(self, X, M):

@@ -9,7 +9,7 @@
 //
 // GEMM view: M = output channels (A = weights, 32 per tile, MT tiles per wave), N = 32 * NT pixels
 // along time, K = (16-channel group, tap).  A workgroup is 8 waves = 8 output rows x 32 NT columns x
-// all output channels.  One pipeline step = (channel group, tap row): its weights [tap col][MT][32][16]
+// all output channels.  One pipeline step = (channel group, weight half, tap row): its weights [tap col][MT][32][16]
 // arrive two steps ahead in a 3-deep LDS ring, the group's input rows one group ahead (two when a
 // tap row is a whole group), so HBM / L2 latency is covered by one or two steps of MFMA work and a
 // step ends with one s_barrier and a counted vmcnt wait -- never a full drain.
@@ -264,9 +264,10 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     const int G = p.G0 + p.G1;
     const int R = p.allrows ? nth : 1;               // tap rows per step
     const int nchunk = nth / R;
-    const int step_bytes = R * ntws * p.hl * MT * 1024;
-    const int n_w_instr = R * ntws * p.hl * MT;
-    const int S = G * nchunk;
+    const int step_bytes = R * ntws * MT * 1024;
+    const int n_w_instr = R * ntws * MT;
+    const int nsub = p.hl * nchunk;                  // steps per channel group: weight half (outer) x tap-row chunk
+    const int S = G * nsub;
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + p.ph[a].w_off), 0, (int)p.ph[a].w_bytes, 0x00020000);
 
     auto issue_input = [&](int g) -> int {            // group g -> its ring slot; returns instructions issued
@@ -335,9 +336,10 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     int s = 0;
     for (int g = 0; g < G; ++g) {
         const char* in_img = s_in + (g % nin_buf) * p.in_buf_bytes;
-        for (int tc = 0; tc < nchunk; ++tc, ++s) {
+        for (int sub = 0; sub < nsub; ++sub, ++s) {
+            const int tc = sub % nchunk;
             int issued = (B16_ABLATE & 2) ? 0 : issue_weights(s + p.wring - 1);
-            if (tc == 0 && !(B16_ABLATE & 2)) issued += issue_input(g + p.din);
+            if (sub == 0 && !(B16_ABLATE & 2)) issued += issue_input(g + p.din);
 
             const char* wimg = s_w + (s % p.wring) * p.w_buf_bytes + a_lane;
             for (int tr = 0; tr < R; ++tr) {
@@ -348,17 +350,15 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         const int ntw_n = nt ? ntw1 : ntw0;
-                        const char* wt0 = wimg + (tr * ntws + (nt ? ntw0 : 0)) * p.hl * MT * 1024;
+                        const char* wt0 = wimg + (tr * ntws + (nt ? ntw0 : 0)) * MT * 1024;
 #pragma unroll 1
                         for (int tw = 0; tw < ((B16_ABLATE & 1) ? 0 : ntw_n); ++tw) {
                             const bf16x8 B = *reinterpret_cast<const bf16x8*>(brow + colb[nt] + tw * p.tdw * 16);
-                            for (int h = 0; h < p.hl; ++h) {
-                                const char* wt = wt0 + (tw * p.hl + h) * MT * 1024;
+                            const char* wt = wt0 + tw * MT * 1024;
 #pragma unroll
-                                for (int mt = 0; mt < MT; ++mt) {
-                                    const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[mt][nt], 0, 0, 0);
-                                }
+                            for (int mt = 0; mt < MT; ++mt) {
+                                const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[mt][nt], 0, 0, 0);
                             }
                         }
                     }
@@ -369,15 +369,13 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             B[nt] = *reinterpret_cast<const bf16x8*>(brow + colb[nt] + tw * p.tdw * 16);
-                        for (int h = 0; h < p.hl; ++h) {
-                            const char* wt = wimg + ((tr * ntws + tw) * p.hl + h) * MT * 1024;
+                        const char* wt = wimg + (tr * ntws + tw) * MT * 1024;
 #pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) {
-                                const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
 #pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[nt], acc[mt][nt], 0, 0, 0);
-                            }
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[nt], acc[mt][nt], 0, 0, 0);
                         }
                     }
                 }
@@ -555,7 +553,7 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     for (int q = 0; q < np; ++q)
         wg64 += (unsigned long long)d.N * ((a.ph[q].rows + kB16Waves - 1) / kB16Waves) * ((a.ph[q].cols[0] + 63) / 64);
     const bool few_wg = wg64 <= 512;
-    const bool allrows_ok = max_nth > 1 && max_nth * max_ntws * hl * pl->MT <= (few_wg ? 48 : 24);
+    const bool allrows_ok = max_nth > 1 && max_nth * max_ntws * pl->MT <= (few_wg ? 48 : 24);
     auto in_bytes = [&](int nt) {                  // largest input image of a channel group over the phases
         const int tw_cols = a.pair ? 32 : 32 * nt;
         int cols_in = 1;
@@ -582,8 +580,8 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     for (int cc = allrows_ok ? 0 : 6; cc < 12 && !found; ++cc) {      // first with whole-group steps, then without
         const int c = cc % 6;                       // 4, 5: one workgroup per CU with rings of 2 (large steps)
         a.allrows = cc < 6 ? 1 : 0;
-        a.w_buf_bytes = (a.allrows ? max_nth : 1) * max_ntws * hl * pl->MT * 1024;
-        const bool single_step_group = a.allrows || one_row_phase;
+        a.w_buf_bytes = (a.allrows ? max_nth : 1) * max_ntws * pl->MT * 1024;
+        const bool single_step_group = (a.allrows || one_row_phase) && hl == 1;
         const int nt = (c & 1) ? 1 : 2;
         const bool occ2 = c < 2;
         const bool shallow = c >= 4;
@@ -669,13 +667,13 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
                 for (int cp = 0; cp < ncp; ++cp)
                     for (int tw = 0; tw < p.ntw[cp]; ++tw) {
                         const int ky = pl.kh0[q] + th * pl.khs, kx = pl.kw0[q][cp] + tw * pl.kws;
-                        const size_t tap = (size_t)(g * p.nth + th) * ntws + (cp ? p.ntw[0] : 0) + tw;
                         for (int h = 0; h < a.hl; ++h)
                             for (int mt = 0; mt < MT; ++mt)
                                 for (int hf = 0; hf < 2; ++hf)
                                     for (int row = 0; row < 32; ++row)
                                         for (int k = 0; k < 8; ++k) {
-                                            const size_t dst = (((((tap * a.hl + h) * MT + mt) * 2 + hf) * 32 + row) * 8) + k;
+                                            const size_t tap = ((size_t)(g * a.hl + h) * p.nth + th) * ntws + (cp ? p.ntw[0] : 0) + tw;
+                                            const size_t dst = ((((tap * MT + mt) * 2 + hf) * 32 + row) * 8) + k;
                                             const int cl = (g < a.G0 ? g : g - a.G0) * 16 + hf * 8 + k;
                                             const int ci = g < a.G0 ? (cl < d->C0 ? cl : -1) : (cl < d->C1 ? d->C0 + cl : -1);
                                             const int co = mt * 32 + row;
