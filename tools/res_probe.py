@@ -32,3 +32,6 @@ for H in (3, 10, 34):
 run("conv(3,1) 128->64 H=3", nn.Conv2d(128, 64, (3, 1), (1, 1), (0, 0)), 3, 501)
 run("conv(3,1) 128->128 H=3", nn.Conv2d(128, 128, (3, 1), (1, 1), (0, 0)), 3, 501)
 run("conv(3,1) 128->384 W=125", nn.Conv2d(128, 384, (3, 1), (1, 1), (0, 0)), 3, 125)
+print("--- one-column kernels of the other networks")
+run("UNet20 dec_9 tconv(7,1) 96->64", nn.ConvTranspose2d(96, 64, (7, 1), (1, 1), (3, 0)), 257, 509)
+run("conv(1,1) 64->32 head", nn.Conv2d(64, 32, 1), 257, 509)

@@ -125,7 +125,10 @@ __device__ __forceinline__ void group_mfma(f32x16 (&acc)[TPG], const float* s_in
         }
         return d;
     };
-    const float* rp[3][TPG];
+    // rows per unrolled block: a one-tap row (one-column kernels, the generic walk) is only TPG MFMAs, so four
+    // of them share one pass of the loop's scalar bookkeeping; wider rows go two at a time
+    constexpr int RW = NTWE == 1 ? 4 : 2;
+    const float* rp[RW + 1][TPG];
 #pragma unroll
     for (int t = 0; t < TPG; ++t) rp[0][t] = s_in + ib[t];
     float a[2], b[2][TPG];
@@ -133,15 +136,30 @@ __device__ __forceinline__ void group_mfma(f32x16 (&acc)[TPG], const float* s_in
 #pragma unroll
     for (int t = 0; t < TPG; ++t) b[0][t] = rp[0][t][0];
     int r = 0;
-    for (; r + 2 <= R; r += 2) {
-        const int d1 = advance();
-        const int d2 = (r + 2 < R) ? advance() : 0;            // past the end: re-read the last row
+    for (; r + RW <= R; r += RW) {
 #pragma unroll
-        for (int t = 0; t < TPG; ++t) { rp[1][t] = rp[0][t] + d1; rp[2][t] = rp[1][t] + d2; }
-        mfma_rows<TPG, NTWE, 2, NB>(acc, a, b, wp, rp, side);
-        wp += 2 * NTWE * 2 * NB;
+        for (int q = 1; q <= RW; ++q) {
+            const int d = (q < RW || r + RW < R) ? advance() : 0;      // past the end: re-read the last row
 #pragma unroll
-        for (int t = 0; t < TPG; ++t) rp[0][t] = rp[2][t];
+            for (int t = 0; t < TPG; ++t) rp[q][t] = rp[q - 1][t] + d;
+        }
+        mfma_rows<TPG, NTWE, RW, NB>(acc, a, b, wp, rp, side);
+        wp += RW * NTWE * 2 * NB;
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) rp[0][t] = rp[RW][t];
+    }
+    if (RW == 4) {
+        for (; r + 2 <= R; r += 2) {
+            const float* two[3][TPG];
+            const int d1 = advance();
+            const int d2 = (r + 2 < R) ? advance() : 0;
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) { two[0][t] = rp[0][t]; two[1][t] = rp[0][t] + d1; two[2][t] = two[1][t] + d2; }
+            mfma_rows<TPG, NTWE, 2, NB>(acc, a, b, wp, two, side);
+            wp += 2 * NTWE * 2 * NB;
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) rp[0][t] = two[2][t];
+        }
     }
     if (r < R) {
         const float* last[2][TPG];
