@@ -57,10 +57,21 @@ def main():
 
     act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
-    def report(name, sec, gflop, workload, dtype="f32"):
+    def report(name, sec, gflop, workload, dtype="f32", bf16_operands=False, hbm_gb=None):
+        """One JSON line.  The roofline entry prices the WHOLE forward against the peak that bounds its dominant
+        kernels: the fp32 or (bfloat16 operands) bf16 dense MFMA peak, or -- ResUNet -- HBM bandwidth over the
+        algorithmic bytes of its residual-block layers (one read + one write of the activation per layer)."""
+        tflops = gflop * B / sec / 1e3
+        if hbm_gb is not None:
+            ach = hbm_gb * B / sec
+            roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                    "note": "algorithmic bytes of the ResBlock layers over the whole forward's time"}
+        else:
+            peak = 2500.0 if bf16_operands else 157.3
+            roof = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak}
         print(json.dumps({"workload": name, "value": B * AUDIO_SECONDS / sec, "unit": "audio-s/s",
                           "ms_per_step": 1e3 * sec, "batch": B, "dtype": dtype,
-                          "gflop_per_utterance": gflop, "tflops": gflop * B / sec / 1e3,
+                          "gflop_per_utterance": gflop, "tflops": tflops, "roofline": roof,
                           "config": workload}), flush=True)
 
     with torch.no_grad():
@@ -81,7 +92,8 @@ def main():
             net.eval().to(dev)
             x = torch.randn((B, 4, 257, 501), generator=g).to(dev).to(act)
             sec = timed(lambda: net(x), args.steps, args.warmup)
-            report("resunet", sec, 46.0, "ResUNet() forward, [B,4,257,501]", args.dtype)
+            report("resunet", sec, 46.0, "ResUNet() forward, [B,4,257,501]", args.dtype,
+                   hbm_gb=0.643 if args.dtype == "bf16" else 1.285)
             del net, x
         if args.only in (None, "dsunet"):
             net = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8))
@@ -93,7 +105,8 @@ def main():
             theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1).to(dev)
             sec = timed(lambda: net(sf, SV, theta), args.steps, args.warmup)
             report("dsunet", sec, 129.76, "DSUNet(UDSS table, model_complexity 45, 8 inputs) forward, "
-                                          "sf [B,8,257,512], SV [B,4,514], theta [B,2]", args.dtype)
+                                          "sf [B,8,257,512], SV [B,4,514], theta [B,2]", args.dtype,
+                   bf16_operands=args.dtype == "bf16")
         if args.only in (None, "helper"):
             net = unet_amd.DSUNet_helper(unet_amd.dsunet_architecture(45, 8))
             unet_amd.seeded_fill_(net, seed=51)
@@ -116,7 +129,8 @@ def main():
             theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1).to(dev)
             sec = timed(lambda: net(sf, SV, theta), args.steps, args.warmup)
             report("udss", sec, round(udss_gflop(), 2), "UDSS(type_norm='BatchNorm2d') complex-valued forward, "
-                                                        "sf [B,4,257,512,2], SV [B,4,514], theta [B,2]", args.dtype)
+                                                        "sf [B,4,257,512,2], SV [B,4,514], theta [B,2]", args.dtype,
+                   bf16_operands=args.dtype == "bf16")
 
 
 def udss_gflop():
