@@ -497,7 +497,8 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     if ((size_t)2 * std::max(a.G0, a.G1) * d.H * d.W * 16 >= (size_t)1 << 31) return bad("conv2d_b16: sample larger than 2 GB");
     int np = 0;
     // a time-stride-2 transposed layer runs its two column phases as the two column tiles of a workgroup
-    a.pair = (d.transposed && d.sw == 2 && pl->MT <= 3 && !(d.act != UNETMI_ACT_NONE && d.act != UNETMI_ACT_LEAKY && d.act != UNETMI_ACT_RELU)) ? 1 : 0;
+    // (geometry only: the weight image depends on it, and the packer does not know the activation)
+    a.pair = (d.transposed && d.sw == 2 && pl->MT <= 3) ? 1 : 0;
     if (!d.transposed) {
         a.sih = d.sh; a.siw = d.sw; a.tdh = d.dh; a.tdw = d.dw; a.soh = 1; a.sow = 1;
         B16Phase& p = a.ph[0];
@@ -706,8 +707,9 @@ int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* 
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipErrorInvalidConfiguration;
     const bool gen = d->act != UNETMI_ACT_NONE && d->act != UNETMI_ACT_LEAKY && d->act != UNETMI_ACT_RELU;
-    if (gen && pl.MT > 1)
-        return api_fail(UNETMI_E_UNSUPPORTED, "conv2d_b16: SiLU / Softplus / Sigmoid / Tanh / GELU epilogues are built for K <= 32 only");
+    if (gen && (pl.MT > 1 || pl.args.pair))
+        return api_fail(UNETMI_E_UNSUPPORTED, "conv2d_b16: SiLU / Softplus / Sigmoid / Tanh / GELU epilogues are built for K <= 32 "
+                                              "and not for time-stride-2 transposed layers");
 #define UNETMI_B16(MT_, NT_, GEN_)                                                                          \
     if (!pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && gen == GEN_ && !pl.occ2) {                         \
         static bool raised = false; e = launch_b16(&conv_b16_kernel<MT_, NT_, GEN_>, &raised, pl, st); }
