@@ -445,6 +445,12 @@ def test_dsunet_helper_wave_to_wave(device):
     assert_close(want, golden, tol=1e-5, what="oracle vs golden")
     assert_close(got, golden, what="helper HIP vs golden")
     assert_close(got, want, what="helper HIP vs oracle")
+    # opt-in: the network inside with bfloat16 operands; everything around it stays fp32
+    dev.bf16_matrix = True
+    with torch.no_grad():
+        got16 = dev(wav.to(device), angle.to(device), mic.to(device))
+    assert got16.dtype == torch.float32 and dev.net._blocked, "the bfloat16-operand path was not taken"
+    assert_bf16_close(got16, want, "helper wave -> wave, bfloat16 operands")
 
 
 @pytest.mark.parametrize("variant,kw", [("gconv", dict(type_encoder="GConv")), ("tgru", dict(bottleneck="TGRU")),

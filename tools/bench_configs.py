@@ -109,6 +109,7 @@ def main():
                    bf16_operands=args.dtype == "bf16")
         if args.only in (None, "helper"):
             net = unet_amd.DSUNet_helper(unet_amd.dsunet_architecture(45, 8))
+            net.bf16_matrix = args.dtype == "bf16"
             unet_amd.seeded_fill_(net, seed=51)
             net.eval().to(dev)
             wav = (torch.randn((B, 4, 64000), generator=g) * 0.1).to(dev)
@@ -116,7 +117,8 @@ def main():
             mic = ((torch.rand((B, 4, 3), generator=g) - 0.5) * 0.1).to(dev)
             sec = timed(lambda: net(wav, angle, mic), args.steps, args.warmup)
             report("helper", sec, 129.76, "DSUNet_helper wave -> wave: 4-channel 4 s 16 kHz audio, STFT + features + "
-                                          "DSUNet + mask + inverse STFT, [B,4,64000] -> [B,64000]")
+                                          "DSUNet + mask + inverse STFT, [B,4,64000] -> [B,64000]", args.dtype,
+                   bf16_operands=args.dtype == "bf16")
             del net, wav, angle, mic
         if args.only in (None, "udss"):
             net = unet_amd.UDSS(type_norm="BatchNorm2d")
