@@ -93,3 +93,54 @@ def test_benchmark_size_batch_against_golden_and_oracle(device):
     with torch.no_grad():
         for i in (31, 63):
             assert_close(got[i:i + 1], ref(x[i:i + 1]), what="sample {} of the batch".format(i))
+
+
+def _bf16_errors(got, want):
+    if got.is_complex():
+        got, want = torch.view_as_real(got), torch.view_as_real(want)
+    got, want = got.detach().cpu().float(), want.detach().cpu().float()
+    return ((got - want).norm() / want.norm()).item(), ((got - want).abs().max() / want.abs().max()).item()
+
+
+def test_unet_and_unet20_bf16_operands(device):
+    """Opt-in (``bf16_matrix``): a bfloat16 input through the whole concat shell with bfloat16 operands (channel-blocked
+    layout, bf16 MFMA), against the fp32 oracle on the same (bf16-representable) input.  Held to relative L2 <= 1e-2;
+    the max-norm error is printed -- for this network it is 2e-2..4e-2 with bfloat16 activations whether the products
+    are bf16 or fp32, which is why the path is not the default."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref, dev = _pair(32, 2, 1, seed=5)
+    dev.to(device)
+    x = normal("unet_bf16/x", (2, 2, 257, 45), seed=6).to(torch.bfloat16)
+    with torch.no_grad():
+        want = ref(x.float())
+        assert dev.bf16_matrix is False
+        stor = dev(x.to(device))
+        dev.bf16_matrix = True
+        got = dev(x.to(device))
+    assert got.dtype == torch.bfloat16 and dev._blocked, "the bfloat16-operand path was not taken"
+    l2, mx = _bf16_errors(got, want)
+    l2s, mxs = _bf16_errors(stor, want)
+    print("UNet bf16 operands: relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+    print("UNet bf16 storage : relative L2 {:.3e}, max-norm {:.3e}".format(l2s, mxs))
+    assert l2 <= 1e-2 and l2s <= 1e-2
+
+    ref20 = oracle.UNet20().eval()
+    unet_amd.seeded_fill_(ref20, seed=21)
+    dev20 = unet_amd.UNet20()
+    dev20.load_state_dict(ref20.state_dict(), strict=True)
+    ref20.T = dev20.T = 29
+    dev20.eval().to(device)
+    x20 = uniform("unet20_bf16/x", (2, 14, 257, 29), 0.0, 1.0, seed=22).to(torch.bfloat16)
+    with torch.no_grad():
+        want20 = ref20(x20.float())
+        stor20 = dev20(x20.to(device))
+        dev20.bf16_matrix = True
+        got20 = dev20(x20.to(device))
+    assert got20.dtype == torch.complex64 and tuple(got20.shape) == tuple(want20.shape) and dev20._blocked
+    l2, mx = _bf16_errors(got20, want20)
+    l2s, mxs = _bf16_errors(stor20, want20)
+    print("UNet20 bf16 operands: relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+    print("UNet20 bf16 storage : relative L2 {:.3e}, max-norm {:.3e}".format(l2s, mxs))
+    assert l2 <= 1e-2 and l2s <= 1e-2

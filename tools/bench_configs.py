@@ -77,14 +77,16 @@ def main():
     with torch.no_grad():
         if args.only in (None, "unet20"):
             net = unet_amd.UNet20()
+            net.bf16_matrix = True                       # with --dtype bf16: bfloat16 operands (opt-in for this network)
             unet_amd.seeded_fill_(net, seed=21)
             net.T = 509
             net.eval().to(dev)
-            x = torch.rand((B, 14, 257, 509), generator=g).to(dev)
+            x = torch.rand((B, 14, 257, 509), generator=g).to(dev).to(act)
             X = torch.view_as_complex(torch.randn((B, 4, 257, 509, 2), generator=g).contiguous()).to(dev)
             sec = timed(lambda: crf_apply(net(x), X), args.steps, args.warmup)
             report("unet20", sec, 76.65, "cRFUNet.UNet20(c_in=14, c_out=4) forward at T=509 + ratio-filter "
-                                         "application, one GPU's share of a batch of 256 over 8 GPUs")
+                                         "application, one GPU's share of a batch of 256 over 8 GPUs", args.dtype,
+                   bf16_operands=args.dtype == "bf16")
             del net, x, X
         if args.only in (None, "resunet"):
             net = unet_amd.ResUNet()

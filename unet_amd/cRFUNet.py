@@ -12,7 +12,7 @@ zero-copy reshape + ``view_as_complex`` on the device tensor.
 import torch
 import torch.nn as nn
 
-from .UNet import concat_shell_forward, register_concat_shell
+from .UNet import blocked_shell_forward, blocked_shell_layers, concat_shell_forward, register_concat_shell
 from .UNet_m import Decoder, Encoder
 from .fused import FusedConv, require_device_tensor
 from .tables import unet20_layers
@@ -35,12 +35,18 @@ class UNet20(nn.Module):
         self.activation_mask = nn.Sigmoid() if mask == "Sigmoid" else nn.Softplus()
         self._head = None
 
+    bf16_matrix = False     # opt-in: bfloat16 inputs take the bfloat16-operand path (see UNet.bf16_matrix)
+
     def forward(self, x):
         require_device_tensor(x, "UNet20")
-        p = concat_shell_forward(self, x)
-        if self._head is None:
-            object.__setattr__(self, "_head", FusedConv(self.linear, None, self.activation_mask))
-        f = self._head(p)                 # [B, 2*c_out*N, F, T], contiguous
+        layers = blocked_shell_layers(self) if (x.dtype == torch.bfloat16 and self.bf16_matrix and not self.training) else False
+        if layers:
+            f = self.activation_mask(blocked_shell_forward(self, layers, x))     # fp32 [B, 2*c_out*N, F, T]
+        else:
+            p = concat_shell_forward(self, x)
+            if self._head is None:
+                object.__setattr__(self, "_head", FusedConv(self.linear, None, self.activation_mask))
+            f = self._head(p).float()         # [B, 2*c_out*N, F, T], contiguous
         f = torch.reshape(f, (f.shape[0], self.N, self.c_out, 2 * self.L_f + 1, 2 * self.L_t + 1,
                               self.F, self.T, 2))
         return torch.view_as_complex(f)
