@@ -59,6 +59,12 @@ CASES = [
     (90, 8, 90, (7, 1), (1, 1), (3, 0), (0, 0), True, 21, 33),
     (16, 0, 32, (3, 3), (1, 1), (1, 2), (0, 0), False, 9, 40),
     (20, 12, 64, (3, 3), (1, 1), (1, 1), (0, 0), False, 12, 65),
+    # edges: one pixel, one channel, tiles hanging over every border, time-only stride, dilation via a wide pad
+    (1, 0, 1, (1, 1), (1, 1), (0, 0), (0, 0), False, 1, 1),
+    (3, 0, 2, (3, 3), (1, 1), (1, 1), (0, 0), False, 2, 3),
+    (16, 0, 16, (1, 3), (1, 2), (0, 1), (0, 1), True, 4, 9),
+    (17, 1, 33, (3, 1), (2, 1), (1, 0), (1, 0), True, 5, 7),
+    (8, 8, 16, (5, 3), (2, 2), (2, 1), (1, 1), True, 1, 1),
 ]
 
 
@@ -118,6 +124,14 @@ def test_conv_b16_matches_cpu(device, case, halves):
     raw = got.data.permute(0, 1, 4, 2, 3).reshape(N, -1, *got.data.shape[2:4])
     if raw.shape[1] > K:
         assert raw[:, K:].float().abs().max().item() == 0.0
+
+
+def test_conv_b16_empty_batch(device):
+    from unet_amd.blocked import BlockedConv, BlockedTensor
+    conv = nn.Conv2d(16, 16, 3, padding=1)
+    x = BlockedTensor(torch.zeros(0, 2, 5, 7, 8, dtype=torch.bfloat16, device=device), 16)
+    y = BlockedConv(conv.to(device), None, None)(x)
+    assert y.shape == (0, 16, 5, 7)
 
 
 def test_conv_b16_rejects(device):
