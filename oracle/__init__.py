@@ -20,7 +20,7 @@ from .blocks import (Encoder, Decoder, ResBlock, DSEncoder, DSDecoder, Attractor
 from .nets import UNet, UNet20, ResUNet, ResUNetOnFreq, ResUNetOnFreq2, LSTMBlock, DSUNet
 from .tables import unet20_layers, default_unet, dsunet_architecture
 from .masking import crf_apply, resunet_mask_apply, crm_apply
-from .helper import DSUNet_helper
+from .helper import DSUNet_helper, UDSS_helper
 from .udss import UDSS, ComplexConv2d, ComplexConvTranspose2d, ComplexBatchNorm2d
 
 __all__ = [
@@ -28,5 +28,5 @@ __all__ = [
     "AttractEncoder", "CRM", "CRM_sig", "CRM_soft", "CM", "GConv", "TrGConv", "TGRUBlock", "SEBlock", "UNet", "UNet20", "ResUNet", "ResUNetOnFreq", "ResUNetOnFreq2", "LSTMBlock", "DSUNet",
     "unet20_layers", "default_unet", "dsunet_architecture",
     "crf_apply", "resunet_mask_apply", "crm_apply", "DSUNet_helper",
-    "UDSS", "ComplexConv2d", "ComplexConvTranspose2d", "ComplexBatchNorm2d",
+    "UDSS", "UDSS_helper", "ComplexConv2d", "ComplexConvTranspose2d", "ComplexBatchNorm2d",
 ]

@@ -90,3 +90,51 @@ class DSUNet_helper(nn.Module):
     def delay_n_sum(self, X, angle, mic_pos):         # DSUNet.py:763-790
         h = torch.unsqueeze(self._phasors(angle, mic_pos, +1), -1)
         return torch.einsum("bcft,bcfl->bft", [X, h])
+
+
+class UDSS_helper(DSUNet_helper):
+    """Wave-in / wave-out wrapper of the complex-valued network (UDSS.py:685-839).  Same transforms, steering
+    vector and delay-and-sum as ``DSUNet_helper``; the spectral feature is ``[B, C, F, T, 2]`` (real and
+    imaginary parts stacked last, UDSS.py:761) and the beamformer output is appended as one complex channel
+    (UDSS.py:763-772)."""
+
+    def __init__(self, n_fft=512, complex=True, dropout=0.0, bottleneck="None", model_complexity=45,
+                 type_encoder="Complex", use_SV=True, mag_phase=False, corr=False, DSB=False, activation="LeakyReLU",
+                 type_norm="BatchNorm2d", type_masking="CRM"):
+        nn.Module.__init__(self)
+        from .udss import UDSS
+        self.n_fft = n_fft
+        self.n_hfft = n_fft // 2 + 1
+        self.n_channel = 4
+        model_channel = self.n_channel + (1 if DSB else 0)
+        self.complex, self.mag_phase, self.use_SV, self.corr, self.DSB = complex, mag_phase, use_SV, corr, DSB
+        self.net = UDSS(input_channels=model_channel, complex=complex, dropout=dropout, bottleneck=bottleneck,
+                        model_complexity=model_complexity, type_encoder=type_encoder, activation=activation,
+                        type_norm=type_norm, type_masking=type_masking)
+        self.sr, self.ss, self.dist = 16000, 340.4, 100
+        self.window = torch.hann_window(self.n_fft)
+
+    def forward(self, x, angle, mic_pos):
+        B, C, L = x.shape
+        x = torch.reshape(x, (B * C, L))
+        X = torch.stft(x, n_fft=self.n_fft, window=self.window.to(x.device), return_complex=True)
+        _, F, T = X.shape
+        short = 16 - T % 16
+        X = torch.nn.functional.pad(X, (0, short))
+        _, F, T = X.shape
+        X = X.reshape(B, C, F, T)
+        if self.corr:
+            for i in range(B):
+                for j in range(C - 1):
+                    X[i, j + 1] = X[i, 0] * X[i, j + 1]
+        SV = self.steering_vector(angle, mic_pos)
+        SV = torch.cat((SV.real, SV.imag), -1)
+        theta = self.anlge_pre(angle)
+        spectral_feature = torch.stack((X.real, X.imag), dim=-1)
+        if self.DSB:
+            dsb = self.delay_n_sum(X, angle, mic_pos)
+            dsb = torch.unsqueeze(torch.stack((dsb.real, dsb.imag), dim=-1), 1)
+            spectral_feature = torch.cat((spectral_feature, dsb), dim=1)
+        mask = self.net(spectral_feature, SV, theta)
+        Y = self.net.masking(X[:, 0], mask)
+        return torch.istft(Y, n_fft=self.n_fft, window=self.window.to(Y.device), length=L)

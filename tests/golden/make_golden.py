@@ -351,6 +351,23 @@ def main():
         udss_out[label] = torch.view_as_real(y_ref).numpy()
     if out is not None:
         save("udss_eval", **udss_out)
+    print("UDSS_helper (STFT -> complex features -> UDSS -> CRM -> iSTFT), plain and with the beamformer channel, B=2 C=4 L=4000")
+    helper_out = {}
+    for label, kw in (("plain", {}), ("dsb", dict(DSB=True))):
+        ref = R_udss.UDSS_helper(**kw)
+        seeded_fill_(ref, seed=66)
+        mine = oracle.UDSS_helper(**kw)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        wav = normal("udss_helper/x", (2, 4, 4000), seed=66) * 0.1
+        angle = uniform("udss_helper/angle", (2,), 0.0, 360.0, seed=66)
+        mic = uniform("udss_helper/mic", (2, 4, 3), -0.05, 0.05, seed=66)
+        ref.eval(), mine.eval()
+        with torch.no_grad():
+            y_ref, y_mine = ref(wav, angle, mic), mine(wav, angle, mic)
+        require_equal(y_ref, y_mine, "UDSS_helper " + label)
+        helper_out[label] = y_ref.numpy()
+    if out is not None:
+        save("udss_helper_eval", **helper_out)
     try:
         R_udss.UDSS()
         udss_default = "ok"

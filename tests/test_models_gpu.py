@@ -182,6 +182,30 @@ def test_udss_matches_golden_and_oracle(device, label, kw):
     assert_close(dev.masking(X.to(device), got), ref.masking(X, want), what="UDSS masking")
 
 
+@pytest.mark.parametrize("label,kw", [("plain", {}), ("dsb", dict(DSB=True))])
+def test_udss_helper_wave_to_wave(device, label, kw):
+    """UDSS_helper end to end (device STFT, complex features, UDSS, mask, inverse STFT) against the golden output of
+    the reference and the oracle."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.UDSS_helper(**kw).eval()
+    unet_amd.seeded_fill_(ref, seed=66)
+    dev = unet_amd.UDSS_helper(**kw)
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    wav = normal("udss_helper/x", (2, 4, 4000), seed=66) * 0.1
+    angle = uniform("udss_helper/angle", (2,), 0.0, 360.0, seed=66)
+    mic = uniform("udss_helper/mic", (2, 4, 3), -0.05, 0.05, seed=66)
+    with torch.no_grad():
+        want = ref(wav, angle, mic)
+        got = dev(wav.to(device), angle.to(device), mic.to(device))
+    golden = torch.from_numpy(load_golden("udss_helper_eval")[label])
+    assert_close(want, golden, tol=1e-5, what="oracle vs golden")
+    assert_close(got, golden, what="UDSS_helper HIP vs golden")
+    assert_close(got, want, what="UDSS_helper HIP vs oracle")
+
+
 def test_udss_bf16(device):
     """UDSS on a bfloat16 input.  Default: widened to fp32, i.e. the fp32 bar.  Opt-in (``bf16_matrix``): bfloat16
     operands on the blocked layout, the 256-real-channel bottleneck encoder split over two launches.  For that

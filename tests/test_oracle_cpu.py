@@ -140,6 +140,20 @@ def test_udss_matches_golden():
         pass
 
 
+def test_udss_helper_matches_golden():
+    gold = load_golden("udss_helper_eval")
+    for label, kw in (("plain", {}), ("dsb", dict(DSB=True))):
+        net = oracle.UDSS_helper(**kw).eval()
+        seeded_fill_(net, seed=66)
+        wav = normal("udss_helper/x", (2, 4, 4000), seed=66) * 0.1
+        angle = uniform("udss_helper/angle", (2,), 0.0, 360.0, seed=66)
+        mic = uniform("udss_helper/mic", (2, 4, 3), -0.05, 0.05, seed=66)
+        with torch.no_grad():
+            y = net(wav, angle, mic)
+        assert tuple(y.shape) == (2, 4000)
+        assert_close(y, torch.from_numpy(gold[label]), tol=CPU_TOL, what="UDSS_helper " + label)
+
+
 def test_dsunet_matches_golden():
     net = oracle.DSUNet(oracle.dsunet_architecture(45, 8)).eval()
     seeded_fill_(net, seed=41)

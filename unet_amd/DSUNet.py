@@ -448,13 +448,25 @@ class DSUNet_helper(nn.Module):
         rad = (-angle) / 180 * torch.pi
         return torch.stack((torch.sin(rad), torch.cos(rad)), 1)
 
+    def _tdoa(self, angle, mic_pos):
+        """Path-length differences [B, C].  Computed on the HOST with the reference's own operations
+        (DSUNet.py:741-750): they are differences of ~100 m distances, so one fp32 ulp of a distance moves the
+        phase at the top bin by 1e-3 rad -- a device reduction that rounds the norm differently would show up at
+        that level in the beamformer channel.  Twelve numbers per call."""
+        ang = angle.detach().float().cpu()
+        mp = mic_pos.detach().float().cpu()
+        B = ang.shape[0]
+        loc_src = torch.zeros(B, 3)
+        loc_src[:, 0] = self.dist * torch.cos((-ang) / 180 * torch.pi) * torch.sin(torch.tensor(90 / 180 * torch.pi))
+        loc_src[:, 1] = self.dist * torch.sin((-ang) / 180 * torch.pi) * torch.sin(torch.tensor(90 / 180 * torch.pi))
+        loc_src[:, 2] = self.dist * torch.cos(torch.tensor((90) / 180 * torch.pi))
+        tdoa = torch.zeros(B, self.n_channel)
+        for i in range(self.n_channel):
+            tdoa[:, i] = torch.norm(mp[:, i] - loc_src)     # one norm over the whole [B,3] difference, as in the reference
+        return (tdoa[:, :] - tdoa[:, 0:1]).to(angle.device)
+
     def _phasors(self, angle, mic_pos, sign):
-        rad = (-angle) / 180 * torch.pi
-        loc_src = torch.stack((self.dist * torch.cos(rad), self.dist * torch.sin(rad), torch.zeros_like(rad)), dim=1)
-        loc_src[:, 2] = self.dist * torch.cos(torch.tensor(torch.pi / 2))
-        # one norm over the whole [B,3] difference per microphone, as the reference computes it
-        dist = torch.stack([torch.linalg.norm(mic_pos[:, i] - loc_src) for i in range(self.n_channel)])
-        tdoa = (dist - dist[0])[None, :].expand(angle.shape[0], -1)                          # [B, C]
+        tdoa = self._tdoa(angle, mic_pos)                                                     # [B, C]
         const = sign * 2 * torch.pi * self.sr / (self.n_fft * self.ss)
         j = torch.arange(self.n_hfft, device=angle.device, dtype=torch.float32)
         phase = tdoa[:, :, None] * j[None, None, :] * const                                   # [B, C, F]

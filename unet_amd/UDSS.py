@@ -479,3 +479,54 @@ class UDSS(nn.Module):
 
     def masking(self, X, M):
         return self.mask.output(X, M)
+
+
+def _helper_base():
+    from .DSUNet import DSUNet_helper
+    return DSUNet_helper
+
+
+class UDSS_helper(_helper_base()):
+    """Wave in, wave out around the complex-valued network, with the reference's constructor and
+    ``forward(x, angle, mic_pos)`` (UDSS.py:685-839).  Transforms, steering vector and delay-and-sum are
+    ``DSUNet_helper``'s (same arithmetic in the reference); the spectral feature is ``[B, C, F, T, 2]``."""
+
+    def __init__(self, n_fft=512, complex=True, dropout=0.0, bottleneck="None", model_complexity=45,
+                 type_encoder="Complex", use_SV=True, mag_phase=False, corr=False, DSB=False, activation="LeakyReLU",
+                 type_norm="BatchNorm2d", type_masking="CRM"):
+        nn.Module.__init__(self)
+        from .stft import DeviceSTFT
+        self.n_fft = n_fft
+        self.n_hfft = n_fft // 2 + 1
+        self.n_channel = 4
+        model_channel = self.n_channel + (1 if DSB else 0)
+        self.complex, self.mag_phase, self.use_SV, self.corr, self.DSB = complex, mag_phase, use_SV, corr, DSB
+        self.net = UDSS(input_channels=model_channel, complex=complex, dropout=dropout, bottleneck=bottleneck,
+                        model_complexity=model_complexity, type_encoder=type_encoder, activation=activation,
+                        type_norm=type_norm, type_masking=type_masking)
+        self.sr, self.ss, self.dist = 16000, 340.4, 100
+        self.window = torch.hann_window(self.n_fft)
+        self._stft = DeviceSTFT(n_fft, self.window)
+
+    def forward(self, x, angle, mic_pos):
+        require_device_tensor(x, "UDSS_helper")
+        B, C, L = x.shape
+        X = self._stft.stft(x.reshape(B * C, L).contiguous())
+        T = X.shape[2]
+        X = torch.nn.functional.pad(X, (0, 16 - T % 16)).reshape(B, C, self.n_hfft, -1)
+        feat_src = X
+        if self.corr:
+            feat_src = torch.cat([X[:, :1], X[:, :1] * X[:, 1:]], dim=1)
+        SV = self.steering_vector(angle, mic_pos)
+        SV = torch.cat((SV.real, SV.imag), -1)
+        theta = self.anlge_pre(angle)
+        feat = feat_src
+        if self.DSB:
+            feat = torch.cat((feat_src, self.delay_n_sum(feat_src, angle, mic_pos)[:, None]), dim=1)
+        spectral_feature = torch.view_as_real(feat.contiguous())            # [B, C(+1), F, T, 2]
+        if self.bf16_matrix:
+            self.net.bf16_matrix = True
+            spectral_feature = spectral_feature.to(torch.bfloat16)
+        mask = self.net(spectral_feature, SV, theta)
+        Y = self.net.masking(feat_src[:, 0], mask)
+        return self._stft.istft(Y.contiguous(), L)
