@@ -397,7 +397,8 @@ class DSUNet_helper(nn.Module):
     (DSUNet.py:634-790).  The two transforms run on the convolution kernels (unet_amd/stft.py), the
     per-frequency Python loops of the reference's steering vector are closed-form tensor expressions,
     and -- as in the reference -- the source distance is one Frobenius norm over the whole batch
-    (DSUNet.py:748), so all samples of a call share their delays."""
+    (DSUNet.py:748), so all samples of a call share their delays.  Those twelve path lengths are computed on
+    the host with the reference's operations (see ``_tdoa``); everything else runs on the device."""
 
     def __init__(self, architecture, n_fft=512, dropout=0.0, bottleneck="None", model_complexity=45, use_SV=True,
                  mag_phase=False, corr=False, DSB=False, activation="LeakyReLU", type_norm="BatchNorm2d",
