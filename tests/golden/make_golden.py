@@ -326,8 +326,20 @@ def main():
         require_equal(ref.steering_vector(angle, mic), mine.steering_vector(angle, mic), "steering vector")
     require_equal(y_ref, y_mine, "DSUNet_helper eval")
     assert tuple(y_ref.shape) == (2, 4000)
+    extra = {}
+    for label, kw, nin in (("dsb", dict(DSB=True), 10), ("corr", dict(corr=True), 8)):
+        arch_v = dsunet_architecture(45, nin)
+        ref = R_ds.DSUNet_helper(arch_v, **kw)
+        seeded_fill_(ref, seed=52)
+        mine = oracle.DSUNet_helper(arch_v, **kw)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        ref.eval(), mine.eval()
+        with torch.no_grad():
+            v_ref, v_mine = ref(wav, angle, mic), mine(wav, angle, mic)
+        require_equal(v_ref, v_mine, "DSUNet_helper " + label)
+        extra[label] = v_ref.numpy()
     if out is not None:
-        save("dsunet_helper_eval", out=y_ref.numpy())
+        save("dsunet_helper_eval", out=y_ref.numpy(), **extra)
 
     # ---------------------------------------------------------------- UDSS (complex-valued family)
     import UDSS as R_udss

@@ -469,6 +469,16 @@ def test_dsunet_helper_wave_to_wave(device):
     assert_close(want, golden, tol=1e-5, what="oracle vs golden")
     assert_close(got, golden, what="helper HIP vs golden")
     assert_close(got, want, what="helper HIP vs oracle")
+    # the beamformer channel and the cross-channel product variants
+    for label, kw, nin in (("dsb", dict(DSB=True), 10), ("corr", dict(corr=True), 8)):
+        ref_v = oracle.DSUNet_helper(oracle.dsunet_architecture(45, nin), **kw).eval()
+        unet_amd.seeded_fill_(ref_v, seed=52)
+        dev_v = unet_amd.DSUNet_helper(unet_amd.dsunet_architecture(45, nin), **kw)
+        dev_v.load_state_dict(ref_v.state_dict(), strict=True)
+        dev_v.eval().to(device)
+        with torch.no_grad():
+            got_v = dev_v(wav.to(device), angle.to(device), mic.to(device))
+        assert_close(got_v, torch.from_numpy(load_golden("dsunet_helper_eval")[label]), what="helper {} HIP vs golden".format(label))
     # opt-in: the network inside with bfloat16 operands; everything around it stays fp32
     dev.bf16_matrix = True
     with torch.no_grad():
