@@ -145,6 +145,67 @@ class UTGRUBlock(nn.Module):
         return self.relu(self.bn(self.conv(y)))
 
 
+class UFGRUBlock(nn.Module):
+    """Bidirectional GRU along FREQUENCY over the interleaved (channel, re/im) features of every (batch, frame),
+    then complex 1x1 conv + complex BatchNorm + PReLU.  Restates UDSS.py:15-37."""
+
+    def __init__(self, in_channels, hidden_size, out_channels):
+        super().__init__()
+        self.GRU = nn.GRU(in_channels * 2, hidden_size * 2, batch_first=True, bidirectional=True)
+        self.conv = ComplexConv2d(hidden_size * 2, out_channels, kernel_size=1)
+        self.bn = ComplexBatchNorm2d(out_channels)
+        self.hidden_size = hidden_size
+        self.relu = nn.PReLU()
+
+    def forward(self, x):
+        B, C, F, T, _ = x.shape
+        seq = x.permute(0, 3, 2, 1, 4).reshape(B * T, F, C * 2)
+        y, _ = self.GRU(seq)
+        y = y.reshape(B, T, F, self.hidden_size * 2, 2).permute(0, 3, 2, 1, 4)
+        return self.relu(self.bn(self.conv(y)))
+
+
+class UFTGRUBlock(nn.Module):
+    """Frequency GRU block, then time GRU block.  Restates UDSS.py:72-83."""
+
+    def __init__(self, in_channels, hidden_size, out_channels, **kwargs):
+        super().__init__()
+        self.FGRU = UFGRUBlock(in_channels, hidden_size, out_channels, **kwargs)
+        self.TGRU = UTGRUBlock(in_channels, hidden_size, out_channels, **kwargs)
+
+    def forward(self, x, rnn_state=None):
+        return self.TGRU(self.FGRU(x), rnn_state)
+
+
+class UcRNN(nn.Module):
+    """Complex recurrent bottleneck from four real GRUs (rr, ri, ir, ii) over the flattened (channel, frequency)
+    features, BatchNorm1d and PReLU per part.  Restates UDSS.py:190-239 (style "GRU"), including its last two
+    lines: the permute (1, 3, 2, 0) of the 4-D [B, C*F, T, 2] tensor yields [C*F, 2, T, B], and that buffer is
+    reshaped to [B, C, F, T, 2] -- the axes come out scrambled, and so they do here."""
+
+    def __init__(self, dim, style="GRU"):
+        super().__init__()
+        cell = {"GRU": nn.GRU, "LSTM": nn.LSTM}[style]
+        self.rr = cell(dim, dim, batch_first=True)
+        self.ri = cell(dim, dim, batch_first=True)
+        self.ir = cell(dim, dim, batch_first=True)
+        self.ii = cell(dim, dim, batch_first=True)
+        self.re_norm = nn.BatchNorm1d(dim)
+        self.im_norm = nn.BatchNorm1d(dim)
+        self.re_activation = nn.PReLU()
+        self.im_activation = nn.PReLU()
+
+    def forward(self, x):
+        B, C, F, T, _ = x.shape
+        x = torch.reshape(torch.permute(x, (4, 0, 3, 1, 2)), (2, B, T, C * F))
+        rr, ri = self.rr(x[0])[0], self.ri(x[0])[0]
+        ir, ii = self.ir(x[1])[0], self.ii(x[1])[0]
+        re = self.re_activation(self.re_norm(torch.permute(rr - ii, (0, 2, 1))))
+        im = self.im_activation(self.im_norm(torch.permute(ri + ir, (0, 2, 1))))
+        y = torch.permute(torch.stack((re, im), dim=-1), (1, 3, 2, 0))
+        return torch.reshape(y, (B, C, F, T, 2))
+
+
 class UCRM(nn.Module):
     """tanh, drop the singleton channel, re/im -> complex.  Restates UDSS.py:91-103."""
 
@@ -186,7 +247,7 @@ class UDSS(nn.Module):
     """Complex-valued directional source separation U-Net: ten complex encoders gated per channel by the
     attractor code, ten complex decoders fed [decoder, skip] concatenated on the channel axis, complex 1x1
     head to one channel, CRM / CM output.  Restates UDSS.py:420-580 for ``complex=True``,
-    ``type_encoder="Complex"`` and the bottlenecks "None" / "TGRU".
+    ``type_encoder="Complex"`` and the bottlenecks "None" / "TGRU" / "FTGRU" / "cRNN".
 
     The reference's default ``type_norm="BatcNorm2d"`` (sic) leaves the norm class unbound and fails at
     construction; callers pass ``type_norm="BatchNorm2d"``.  Decoders are built without ``type_norm`` and so
@@ -220,9 +281,13 @@ class UDSS(nn.Module):
                          activation=activation) for i in range(L)]
         for i, m in enumerate(decs):
             self.add_module("decoder{}".format(i), m)
-        if bottleneck == "TGRU":
+        if bottleneck == "cRNN":
+            self.BTN = UcRNN(128 * 2)
+        elif bottleneck == "TGRU":
             self.BTN = UTGRUBlock(128, 256, 128)
-        elif bottleneck in ("cRNN", "FTGRU", "RNN_AS", "AATT"):
+        elif bottleneck == "FTGRU":
+            self.BTN = UFTGRUBlock(128, 256, 128)
+        elif bottleneck in ("RNN_AS", "AATT"):
             raise NotImplementedError("bottleneck {} is not restated".format(bottleneck))
         else:
             self.BTN = nn.Identity()

@@ -344,7 +344,8 @@ def main():
     # ---------------------------------------------------------------- UDSS (complex-valued family)
     import UDSS as R_udss
     udss_out = {}
-    for label, kw in (("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU"))):
+    for label, kw in (("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU")),
+                      ("ftgru", dict(bottleneck="FTGRU")), ("crnn", dict(bottleneck="cRNN"))):
         print("UDSS(type_norm='BatchNorm2d', {}), B=2 C=4 F=257 T=16 complex".format(kw))
         ref = R_udss.UDSS(type_norm="BatchNorm2d", **kw)
         seeded_fill_(ref, seed=61)

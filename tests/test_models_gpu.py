@@ -153,7 +153,8 @@ def test_resunet_onfreq2_matches_golden_and_oracle(device):
                      what="ResUNetOnFreq2 {} HIP vs golden".format(label))
 
 
-@pytest.mark.parametrize("label,kw", [("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU"))])
+@pytest.mark.parametrize("label,kw", [("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU")),
+                                      ("ftgru", dict(bottleneck="FTGRU")), ("crnn", dict(bottleneck="cRNN"))])
 def test_udss_matches_golden_and_oracle(device, label, kw):
     """The complex-valued family: every complex conv / transposed conv (+ both BatchNorms, activation, gate,
     skip concat) is one real-convolution launch on the stacked [re | im] tensor."""

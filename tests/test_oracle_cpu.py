@@ -121,7 +121,8 @@ def test_resunet_onfreq2_matches_golden():
 
 def test_udss_matches_golden():
     gold = load_golden("udss_eval")
-    for label, kw in (("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU"))):
+    for label, kw in (("crm", {}), ("cm", dict(type_masking="CM")), ("tgru", dict(bottleneck="TGRU")),
+                      ("ftgru", dict(bottleneck="FTGRU")), ("crnn", dict(bottleneck="cRNN"))):
         net = oracle.UDSS(type_norm="BatchNorm2d", **kw).eval()
         seeded_fill_(net, seed=61)
         sf = normal("udss/sf", (2, 4, 257, 16, 2), seed=61)

@@ -321,6 +321,83 @@ class TGRUBlock(_ComplexBlock):
         return unstack_complex(self.forward_stacked(stack_complex(x), rnn_state))
 
 
+class FGRUBlock(_ComplexBlock):
+    """Bidirectional GRU along frequency for every (batch, frame) (torch's device GRU), then complex 1x1 conv +
+    complex BatchNorm + PReLU as one launch (UDSS.py:15-37)."""
+
+    def __init__(self, in_channels, hidden_size, out_channels):
+        super().__init__()
+        self.GRU = nn.GRU(in_channels * 2, hidden_size * 2, batch_first=True, bidirectional=True)
+        self.conv = ComplexConv2d(hidden_size * 2, out_channels, kernel_size=1)
+        self.bn = ComplexBatchNorm2d(out_channels)
+        self.hidden_size = hidden_size
+        self.relu = nn.PReLU()
+        self._layer = None
+
+    def forward_stacked(self, x):
+        B, C2, F, T = x.shape
+        C = C2 // 2
+        seq = x.reshape(B, 2, C, F, T).permute(0, 4, 3, 2, 1).reshape(B * T, F, C2)      # feature index c*2 + re/im
+        y, _ = self.GRU(seq.float())
+        H2 = self.hidden_size * 2
+        y = y.reshape(B, T, F, H2, 2).permute(0, 4, 3, 2, 1).reshape(B, 2 * H2, F, T).contiguous().to(x.dtype)
+        return self._stacked(self.conv, y)
+
+    def forward(self, x):
+        require_device_tensor(x, "UDSS.FGRUBlock")
+        return unstack_complex(self.forward_stacked(stack_complex(x)))
+
+
+class FTGRUBlock(nn.Module):
+    """UDSS.py:72-83."""
+
+    def __init__(self, in_channels, hidden_size, out_channels, **kwargs):
+        super().__init__()
+        self.FGRU = FGRUBlock(in_channels, hidden_size, out_channels, **kwargs)
+        self.TGRU = TGRUBlock(in_channels, hidden_size, out_channels, **kwargs)
+
+    def forward_stacked(self, x, rnn_state=None):
+        return self.TGRU.forward_stacked(self.FGRU.forward_stacked(x), rnn_state)
+
+    def forward(self, x, rnn_state=None):
+        require_device_tensor(x, "UDSS.FTGRUBlock")
+        return unstack_complex(self.forward_stacked(stack_complex(x), rnn_state))
+
+
+class cRNN(nn.Module):
+    """Four real GRUs combined as a complex recurrence, BatchNorm1d and PReLU per part (UDSS.py:190-239); torch's
+    device RNN and elementwise ops on the stacked tensor."""
+
+    def __init__(self, dim, style="GRU"):
+        super().__init__()
+        cell = {"GRU": nn.GRU, "LSTM": nn.LSTM}[style]
+        self.rr = cell(dim, dim, batch_first=True)
+        self.ri = cell(dim, dim, batch_first=True)
+        self.ir = cell(dim, dim, batch_first=True)
+        self.ii = cell(dim, dim, batch_first=True)
+        self.re_norm = nn.BatchNorm1d(dim)
+        self.im_norm = nn.BatchNorm1d(dim)
+        self.re_activation = nn.PReLU()
+        self.im_activation = nn.PReLU()
+
+    def forward_stacked(self, x):
+        B, C2, F, T = x.shape
+        C = C2 // 2
+        parts = x.float().reshape(B, 2, C * F, T).permute(1, 0, 3, 2)                      # [2, B, T, C*F]
+        rr, ri = self.rr(parts[0])[0], self.ri(parts[0])[0]
+        ir, ii = self.ir(parts[1])[0], self.ii(parts[1])[0]
+        re = self.re_activation(self.re_norm(torch.permute(rr - ii, (0, 2, 1))))           # [B, C*F, T]
+        im = self.im_activation(self.im_norm(torch.permute(ri + ir, (0, 2, 1))))
+        # the reference permutes the 4-D [B, C*F, T, 2] tensor with (1, 3, 2, 0) -- giving [C*F, 2, T, B] -- and then
+        # reshapes THAT buffer to [B, C, F, T, 2] (UDSS.py:236-238): a scramble of the axes, reproduced as it is
+        y = torch.permute(torch.stack((re, im), dim=-1), (1, 3, 2, 0)).reshape(B, C, F, T, 2)
+        return stack_complex(y).to(x.dtype)
+
+    def forward(self, x):
+        require_device_tensor(x, "UDSS.cRNN")
+        return unstack_complex(self.forward_stacked(stack_complex(x)))
+
+
 class CRM(nn.Module):
     """UDSS.py:91-103."""
 
@@ -359,7 +436,7 @@ def udss_table(model_complexity, input_channels):
 
 
 class UDSS(nn.Module):
-    """``complex=True``, ``type_encoder="Complex"``, bottleneck "None" or "TGRU", masks "CRM" / "CM".  As in the
+    """``complex=True``, ``type_encoder="Complex"``, bottleneck "None" / "TGRU" / "FTGRU" / "cRNN", masks "CRM" / "CM".  As in the
     reference the default ``type_norm`` ("BatcNorm2d", sic) fails at construction; pass "BatchNorm2d"."""
 
     def __init__(self, input_channels=4, n_fft=512, complex=True, model_complexity=45, bottleneck="None",
@@ -389,9 +466,13 @@ class UDSS(nn.Module):
                         activation=activation) for i in range(L)]
         for i, m in enumerate(decs):
             self.add_module("decoder{}".format(i), m)
-        if bottleneck == "TGRU":
+        if bottleneck == "cRNN":
+            self.BTN = cRNN(128 * 2)
+        elif bottleneck == "TGRU":
             self.BTN = TGRUBlock(128, 256, 128)
-        elif bottleneck in ("cRNN", "FTGRU", "RNN_AS", "AATT"):
+        elif bottleneck == "FTGRU":
+            self.BTN = FTGRUBlock(128, 256, 128)
+        elif bottleneck in ("RNN_AS", "AATT"):
             raise NotImplementedError("UDSS: bottleneck {} is not built".format(bottleneck))
         else:
             self.BTN = nn.Identity()
@@ -443,7 +524,7 @@ class UDSS(nn.Module):
         for i, enc in enumerate(self.encoders):
             skips.append(x)
             x = enc.forward_stacked(x, self.attractEncoders[i](attract).float().contiguous())
-        p = self.BTN.forward_stacked(x) if isinstance(self.BTN, TGRUBlock) else x
+        p = x if isinstance(self.BTN, nn.Identity) else self.BTN.forward_stacked(x)
         for i, dec in enumerate(self.decoders):
             p = dec.forward_stacked(p, None if i == 0 else skips[L - i])
         if self._head is None:
