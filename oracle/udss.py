@@ -228,6 +228,48 @@ class UCM(nn.Module):
         return M
 
 
+class UCMEA(nn.Module):
+    """Complex mask estimation and application: three (3,1) convolutions on |x|, Re x, Im x give a magnitude mask
+    and a complex mask; ``output`` applies sigmoid(magnitude mask) to the feature's magnitude, then the complex
+    mask as sigmoid(|m|) and a phase rotation, with the reference's own atan2 (UDSS.py:120-177)."""
+
+    def __init__(self, in_channels=1, mag_f_dim=3):
+        super().__init__()
+        self.mag_mask = nn.Conv2d(in_channels, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.real_mask = nn.Conv2d(in_channels, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.imag_mask = nn.Conv2d(in_channels, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.mag_f_dim = mag_f_dim
+
+    @staticmethod
+    def custom_atan2(y, x):
+        pi = torch.tensor([torch.pi], dtype=y.dtype, device=y.device)
+        ans = torch.atan(y / (x + 1e-6))
+        ans += ((y > 0) & (x < 0)) * pi
+        ans -= ((y < 0) & (x < 0)) * pi
+        ans *= 1 - ((y > 0) & (x == 0)) * 1.0
+        ans += ((y > 0) & (x == 0)) * (pi / 2)
+        ans *= 1 - ((y < 0) & (x == 0)) * 1.0
+        ans += ((y < 0) & (x == 0)) * (-pi / 2)
+        return ans
+
+    def forward(self, x):
+        mag_mask = self.mag_mask(torch.sqrt(x[..., 0] ** 2 + x[..., 1] ** 2)).squeeze(1)
+        real_mask = self.real_mask(x[..., 0]).squeeze(1)
+        imag_mask = self.imag_mask(x[..., 1]).squeeze(1)
+        return (mag_mask, real_mask, imag_mask)
+
+    def output(self, feature, mask, eps=1e-9):
+        mag_mask, real_mask, imag_mask = mask
+        mag = torch.abs(feature)
+        pha = self.custom_atan2(feature.imag, feature.real)
+        mag = mag * torch.sigmoid(mag_mask)
+        mag_mask = torch.sqrt(torch.clamp(real_mask ** 2 + imag_mask ** 2, eps))
+        pha_mask = self.custom_atan2(imag_mask + eps, real_mask + eps)
+        real = mag * mag_mask.sigmoid() * torch.cos(pha + pha_mask)
+        imag = mag * mag_mask.sigmoid() * torch.sin(pha + pha_mask)
+        return torch.stack([real, imag], dim=-1)
+
+
 def udss_table(model_complexity, input_channels):
     """Layer table of ``UDSS.set_size`` (UDSS.py:582-683)."""
     mc = model_complexity
@@ -299,6 +341,8 @@ class UDSS(nn.Module):
         self.padding_mode = padding_mode
         if type_masking == "CRM":
             self.mask = UCRM()
+        elif type_masking == "CMEA":
+            self.mask = UCMEA()
         elif type_masking == "CM":
             self.mask = UCM()
         else:

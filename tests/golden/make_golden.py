@@ -362,6 +362,30 @@ def main():
         require_equal(y_ref, y_mine, "UDSS " + label)
         assert tuple(y_ref.shape) == (2, 257, 16) and y_ref.dtype == torch.complex64
         udss_out[label] = torch.view_as_real(y_ref).numpy()
+    print("UDSS(type_masking='CMEA'): three masks and their application")
+    ref = R_udss.UDSS(type_norm="BatchNorm2d", type_masking="CMEA")
+    seeded_fill_(ref, seed=61)
+    mine = oracle.UDSS(type_norm="BatchNorm2d", type_masking="CMEA")
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    ref.eval(), mine.eval()
+    Xm = torch.complex(normal("udss/Xr", (2, 257, 16), seed=62), normal("udss/Xi", (2, 257, 16), seed=62))
+    with torch.no_grad():
+        m_ref, m_mine = ref(sf, SV, theta), mine(sf, SV, theta)
+        for a_, b_, nm in zip(m_ref, m_mine, ("mag", "real", "imag")):
+            require_equal(a_, b_, "UDSS CMEA " + nm + " mask")
+        o_ref, o_mine = ref.masking(Xm, m_ref), mine.masking(Xm, m_mine)
+    require_equal(o_ref, o_mine, "UDSS CMEA applied")
+    udss_out["cmea_masks"] = torch.stack(m_ref).numpy()
+    udss_out["cmea_applied"] = o_ref.numpy()
+    for bn_kind in ("RNN_AS", "AATT"):
+        try:
+            net = R_udss.UDSS(type_norm="BatchNorm2d", bottleneck=bn_kind).eval()
+            with torch.no_grad():
+                net(sf, SV, theta)
+            udss_out_fact = "ok"
+        except Exception as e:  # noqa: BLE001
+            udss_out_fact = type(e).__name__
+        print("  UDSS(bottleneck={!r}) forward: {}".format(bn_kind, udss_out_fact))
     if out is not None:
         save("udss_eval", **udss_out)
     print("UDSS_helper (STFT -> complex features -> UDSS -> CRM -> iSTFT), plain and with the beamformer channel, B=2 C=4 L=4000")

@@ -207,6 +207,38 @@ def test_udss_helper_wave_to_wave(device, label, kw):
     assert_close(got, want, what="UDSS_helper HIP vs oracle")
 
 
+def test_udss_cmea_masks_and_application(device):
+    """UDSS with the CMEA head: the three masks, and their application to a spectrum, against golden and oracle."""
+    import numpy as np
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.UDSS(type_norm="BatchNorm2d", type_masking="CMEA").eval()
+    unet_amd.seeded_fill_(ref, seed=61)
+    dev = unet_amd.UDSS(type_norm="BatchNorm2d", type_masking="CMEA")
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    assert list(dev.state_dict().keys()) == list(ref.state_dict().keys())
+    dev.eval().to(device)
+    sf = normal("udss/sf", (2, 4, 257, 16, 2), seed=61)
+    SV = normal("udss/SV", (2, 4, 514), seed=61)
+    ang = uniform("udss/theta", (2,), 0.0, 2 * np.pi, seed=61)
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    X = torch.complex(normal("udss/Xr", (2, 257, 16), seed=62), normal("udss/Xi", (2, 257, 16), seed=62))
+    with torch.no_grad():
+        want = ref(sf, SV, theta)
+        got = dev(sf.to(device), SV.to(device), theta.to(device))
+        applied = dev.masking(X.to(device), got)
+    gold = load_golden("udss_eval")
+    assert isinstance(got, tuple) and len(got) == 3
+    for g, w, nm in zip(got, want, ("magnitude", "real", "imaginary")):
+        assert_close(g, w, what="UDSS CMEA {} mask vs oracle".format(nm))
+    assert_close(torch.stack([g.cpu() for g in got]), torch.from_numpy(gold["cmea_masks"]), what="UDSS CMEA masks vs golden")
+    # the application goes through atan2 of the masks: a point where a mask component crosses zero turns a 1e-6
+    # difference into a phase jump, so it is compared in the L2 sense
+    a, b = applied.cpu(), torch.from_numpy(gold["cmea_applied"])
+    assert ((a - b).norm() / b.norm()).item() <= 1e-4
+
+
 def test_udss_bf16(device):
     """UDSS on a bfloat16 input.  Default: widened to fp32, i.e. the fp32 bar.  Opt-in (``bf16_matrix``): bfloat16
     operands on the blocked layout, the 256-real-channel bottleneck encoder split over two launches.  For that

@@ -133,6 +133,14 @@ def test_udss_matches_golden():
             y = net(sf, SV, theta)
         assert y.dtype == torch.complex64 and tuple(y.shape) == (2, 257, 16)
         assert_close(torch.view_as_real(y), torch.from_numpy(gold[label]), tol=CPU_TOL, what="UDSS " + label)
+    net = oracle.UDSS(type_norm="BatchNorm2d", type_masking="CMEA").eval()
+    seeded_fill_(net, seed=61)
+    X = torch.complex(normal("udss/Xr", (2, 257, 16), seed=62), normal("udss/Xi", (2, 257, 16), seed=62))
+    with torch.no_grad():
+        masks = net(sf, SV, theta)
+        applied = net.masking(X, masks)
+    assert_close(torch.stack(masks), torch.from_numpy(gold["cmea_masks"]), tol=CPU_TOL, what="UDSS CMEA masks")
+    assert_close(applied, torch.from_numpy(gold["cmea_applied"]), tol=CPU_TOL, what="UDSS CMEA applied")
     # the reference's default type_norm is a misspelt name that leaves the norm class unbound
     try:
         oracle.UDSS()

@@ -420,6 +420,53 @@ class CM(nn.Module):
         return M
 
 
+class CMEA(nn.Module):
+    """UDSS.py:120-177.  ``forward`` takes the head's ``[B, 1, F, T, 2]`` output; on the device the three (3,1)
+    convolutions run on the thin-layer kernel, ``output`` is elementwise torch arithmetic."""
+
+    def __init__(self, in_channels=1, mag_f_dim=3):
+        super().__init__()
+        self.mag_mask = nn.Conv2d(in_channels, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.real_mask = nn.Conv2d(in_channels, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.imag_mask = nn.Conv2d(in_channels, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.mag_f_dim = mag_f_dim
+        self._fused = None
+
+    @staticmethod
+    def custom_atan2(y, x):
+        pi = torch.tensor([torch.pi], dtype=y.dtype, device=y.device)
+        ans = torch.atan(y / (x + 1e-6))
+        ans += ((y > 0) & (x < 0)) * pi
+        ans -= ((y < 0) & (x < 0)) * pi
+        ans *= 1 - ((y > 0) & (x == 0)) * 1.0
+        ans += ((y > 0) & (x == 0)) * (pi / 2)
+        ans *= 1 - ((y < 0) & (x == 0)) * 1.0
+        ans += ((y < 0) & (x == 0)) * (-pi / 2)
+        return ans
+
+    def from_parts(self, re, im):
+        """re, im: [B, C, F, T] fp32 device tensors."""
+        if self._fused is None:
+            object.__setattr__(self, "_fused", tuple(FusedConv(m) for m in (self.mag_mask, self.real_mask, self.imag_mask)))
+        mag = torch.sqrt(re ** 2 + im ** 2).contiguous()
+        return tuple(f(t.contiguous()).squeeze(1) for f, t in zip(self._fused, (mag, re, im)))
+
+    def forward(self, x):
+        require_device_tensor(x, "CMEA")
+        return self.from_parts(x[..., 0], x[..., 1])
+
+    def output(self, feature, mask, eps=1e-9):
+        mag_mask, real_mask, imag_mask = mask
+        mag = torch.abs(feature)
+        pha = self.custom_atan2(feature.imag, feature.real)
+        mag = mag * torch.sigmoid(mag_mask)
+        mag_mask = torch.sqrt(torch.clamp(real_mask ** 2 + imag_mask ** 2, eps))
+        pha_mask = self.custom_atan2(imag_mask + eps, real_mask + eps)
+        real = mag * mag_mask.sigmoid() * torch.cos(pha + pha_mask)
+        imag = mag * mag_mask.sigmoid() * torch.sin(pha + pha_mask)
+        return torch.stack([real, imag], dim=-1)
+
+
 def udss_table(model_complexity, input_channels):
     """Layer table of ``UDSS.set_size`` (UDSS.py:582-683)."""
     mc = model_complexity
@@ -436,7 +483,7 @@ def udss_table(model_complexity, input_channels):
 
 
 class UDSS(nn.Module):
-    """``complex=True``, ``type_encoder="Complex"``, bottleneck "None" / "TGRU" / "FTGRU" / "cRNN", masks "CRM" / "CM".  As in the
+    """``complex=True``, ``type_encoder="Complex"``, bottleneck "None" / "TGRU" / "FTGRU" / "cRNN", masks "CRM" / "CM" / "CMEA".  As in the
     reference the default ``type_norm`` ("BatcNorm2d", sic) fails at construction; pass "BatchNorm2d"."""
 
     def __init__(self, input_channels=4, n_fft=512, complex=True, model_complexity=45, bottleneck="None",
@@ -484,6 +531,8 @@ class UDSS(nn.Module):
         self.padding_mode = padding_mode
         if type_masking == "CRM":
             self.mask = CRM()
+        elif type_masking == "CMEA":
+            self.mask = CMEA()
         elif type_masking == "CM":
             self.mask = CM()
         else:
@@ -531,6 +580,8 @@ class UDSS(nn.Module):
             act = nn.Tanh() if isinstance(self.mask, CRM) else None
             object.__setattr__(self, "_head", _ComplexLayer(self.linear, None, act))
         m = self._head(p).float()                                       # [B, 2, F, T]: re, im (squashed for CRM)
+        if isinstance(self.mask, CMEA):
+            return self.mask.from_parts(m[:, 0:1], m[:, 1:2])
         return torch.complex(m[:, 0, ...], m[:, 1, ...])
 
     def _forward_blocked(self, sf, attract):
@@ -556,6 +607,8 @@ class UDSS(nn.Module):
         m = head._plain.blocked(x, nchw_out=True, halves=self.bf16_weight_halves)     # fp32 [B, 2, F, T]
         if isinstance(self.mask, CRM):
             m = torch.tanh(m)
+        if isinstance(self.mask, CMEA):
+            return self.mask.from_parts(m[:, 0:1], m[:, 1:2])
         return torch.complex(m[:, 0, ...], m[:, 1, ...])
 
     def masking(self, X, M):
