@@ -16,7 +16,8 @@ oracle where the reference checkout is absent (the GPU box).
 """
 
 from .blocks import (Encoder, Decoder, ResBlock, DSEncoder, DSDecoder, Attractor,
-                     AttractEncoder, CRM, CRM_sig, CRM_soft, CM, GConv, TrGConv, TGRUBlock, SEBlock)
+                     AttractEncoder, CRM, CRM_sig, CRM_soft, CM, GConv, TrGConv, TGRUBlock, SEBlock,
+                     MultiScaleConvBlock, GlobalChannelLayerNorm, DepthwiseSeparableConv2d, MEA, custom_atan2)
 from .nets import UNet, UNet20, ResUNet, ResUNetOnFreq, ResUNetOnFreq2, LSTMBlock, DSUNet
 from .tables import unet20_layers, default_unet, dsunet_architecture
 from .masking import crf_apply, resunet_mask_apply, crm_apply
@@ -25,7 +26,7 @@ from .udss import UDSS, ComplexConv2d, ComplexConvTranspose2d, ComplexBatchNorm2
 
 __all__ = [
     "Encoder", "Decoder", "ResBlock", "DSEncoder", "DSDecoder", "Attractor",
-    "AttractEncoder", "CRM", "CRM_sig", "CRM_soft", "CM", "GConv", "TrGConv", "TGRUBlock", "SEBlock", "UNet", "UNet20", "ResUNet", "ResUNetOnFreq", "ResUNetOnFreq2", "LSTMBlock", "DSUNet",
+    "AttractEncoder", "CRM", "CRM_sig", "CRM_soft", "CM", "GConv", "TrGConv", "TGRUBlock", "SEBlock", "MultiScaleConvBlock", "GlobalChannelLayerNorm", "DepthwiseSeparableConv2d", "MEA", "custom_atan2", "UNet", "UNet20", "ResUNet", "ResUNetOnFreq", "ResUNetOnFreq2", "LSTMBlock", "DSUNet",
     "unet20_layers", "default_unet", "dsunet_architecture",
     "crf_apply", "resunet_mask_apply", "crm_apply", "DSUNet_helper",
     "UDSS", "UDSS_helper", "ComplexConv2d", "ComplexConvTranspose2d", "ComplexBatchNorm2d",

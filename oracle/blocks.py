@@ -339,3 +339,97 @@ class CM(nn.Module):
 
     def output(self, X, M):
         return M
+
+
+class DepthwiseSeparableConv2d(nn.Module):
+    """Per-channel conv -> BN -> ReLU -> 1x1 conv -> BN -> ReLU.  Restates UNet_m.py:7-31."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.depthwise = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                   groups=in_channels)
+        self.bn_depth = nn.BatchNorm2d(out_channels)
+        self.pointwise = nn.Conv2d(out_channels, out_channels, kernel_size=1)
+        self.bn_point = nn.BatchNorm2d(out_channels)
+
+    def forward(self, x):
+        x = torch.relu(self.bn_depth(self.depthwise(x)))
+        return torch.relu(self.bn_point(self.pointwise(x)))
+
+
+class GlobalChannelLayerNorm(nn.Module):
+    """One mean and one variance per sample over every other axis, then a per-channel gain and offset.
+    Restates UNet_m.py:739-763."""
+
+    def __init__(self, channel_size):
+        super().__init__()
+        self.channel_size = channel_size
+        self.gamma = nn.Parameter(torch.ones(channel_size))
+        self.beta = nn.Parameter(torch.zeros(channel_size))
+
+    def forward(self, x):
+        dims = list(range(1, x.dim()))
+        mean = x.mean(dim=dims, keepdim=True)
+        var = torch.pow(x - mean, 2).mean(dim=dims, keepdim=True)
+        normed = (x - mean) / (var + 1e-8).sqrt()
+        return (self.gamma * normed.transpose(1, -1) + self.beta).transpose(1, -1)
+
+
+class MultiScaleConvBlock(nn.Module):
+    """1x1 expand -> norm -> depthwise-separable 1x1 -> norm -> 1x1 reduce -> norm.  Restates UNet_m.py:771-788."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        c = in_channels
+        self.net = nn.Sequential(nn.Conv2d(c, 2 * c, kernel_size=1), GlobalChannelLayerNorm(2 * c),
+                                 DepthwiseSeparableConv2d(2 * c, 2 * c, kernel_size=1), GlobalChannelLayerNorm(2 * c),
+                                 nn.Conv2d(2 * c, c, kernel_size=1), GlobalChannelLayerNorm(c))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def custom_atan2(y, x):
+    """Four-quadrant arctangent from ``atan(y / (x + 1e-6))`` and sign tests.  Restates UNet_m.py:677-686."""
+    pi = torch.tensor([3.141592653589793], dtype=torch.float64).to(y.device, y.dtype)
+    ans = torch.atan(y / (x + 1e-6))
+    ans += ((y > 0) & (x < 0)) * pi
+    ans -= ((y < 0) & (x < 0)) * pi
+    ans *= 1 - ((y > 0) & (x == 0)) * 1.0
+    ans += ((y > 0) & (x == 0)) * (pi / 2)
+    ans *= 1 - ((y < 0) & (x == 0)) * 1.0
+    ans += ((y < 0) & (x == 0)) * (-pi / 2)
+    return ans
+
+
+class MEA(nn.Module):
+    """Mask estimation and application: three (3,1) convolutions give a ``mag_f_dim``-row magnitude mask, a
+    real and an imaginary mask; ``output`` gathers each bin's magnitude with its frequency neighbours,
+    weights them by the rectified magnitude mask, then rotates and scales by the complex mask.
+    Restates UNet_m.py:691-732.  ``forward`` is pinned bit-exact; ``output`` is PARITY UNPINNED: the reference's
+    own raises NameError (its ``custom_atan2`` uses numpy, which UNet_m.py never imports), so there is nothing to
+    compare with -- it restates the arithmetic as written."""
+
+    def __init__(self, in_channels=4, mag_f_dim=3):
+        super().__init__()
+        self.mag_mask = nn.Conv2d(in_channels, mag_f_dim, kernel_size=(3, 1), padding=(1, 0))
+        self.real_mask = nn.Conv2d(in_channels, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.imag_mask = nn.Conv2d(in_channels, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.register_buffer("kernel", torch.eye(mag_f_dim).reshape(mag_f_dim, 1, mag_f_dim, 1))
+        self.mag_f_dim = mag_f_dim
+
+    def forward(self, x):
+        return (self.mag_mask(x), self.real_mask(x).squeeze(1), self.imag_mask(x).squeeze(1))
+
+    def output(self, mask, feature, eps=1e-9):
+        mag_mask, real_mask, imag_mask = mask[0], mask[1], mask[2]
+        mag = torch.norm(feature, dim=-1)
+        pha = custom_atan2(feature[..., 1], feature[..., 0])
+        h = (self.mag_f_dim - 1) // 2
+        mag = nn.functional.conv2d(nn.functional.pad(mag[:, None], [0, 0, h, h]), self.kernel)
+        mag = (mag * mag_mask.relu()).sum(dim=1)
+        mag_mask = torch.sqrt(torch.clamp(real_mask ** 2 + imag_mask ** 2, eps))
+        pha_mask = custom_atan2(imag_mask + eps, real_mask + eps)
+        real = mag * mag_mask.relu() * torch.cos(pha + pha_mask)
+        imag = mag * mag_mask.relu() * torch.sin(pha + pha_mask)
+        return torch.stack([real, imag], dim=-1)

@@ -8,7 +8,8 @@ import torch
 import torch.nn as nn
 
 from .blocks import (Encoder, Decoder, ResBlock, DSEncoder, DSDecoder, Attractor,
-                     AttractEncoder, CRM, CRM_sig, CRM_soft, CM, GConv, TrGConv, TGRUBlock, SEBlock)
+                     AttractEncoder, CRM, CRM_sig, CRM_soft, CM, GConv, TrGConv, TGRUBlock, SEBlock,
+                     MultiScaleConvBlock, MEA)
 from .tables import unet20_layers
 
 
@@ -290,8 +291,13 @@ class LSTMBlock(nn.Module):
 
 class ResUNetOnFreq2(nn.Module):
     """ResUNetOnFreq cut after its 30-channel blocks: six encoders down to 7 frequency rows, an LSTM over the
-    flattened (channel, frequency) features, six decoders, one-channel mask.  Restates ResUNet.py:394-591 for
-    ``multi_scale=False`` and the LSTM bottleneck.
+    flattened (channel, frequency) features, six decoders, one-channel mask.  Restates ResUNet.py:394-591 with
+    the LSTM bottleneck.
+
+    ``multi_scale=True`` registers average pools, a ``MultiScaleConvBlock`` and upsamplers and runs the pools
+    and the block beside the encoders (ResUNet.py:447-467, :553-560); nothing downstream reads their result,
+    so the network's output does not depend on them.  ``activation="MEA"`` puts the MEA head on the output
+    (three masks); the reference's ``output`` then names an attribute that does not exist (ResUNet.py:589).
 
     The reference indexes the bottleneck's output tensor with ``[0]`` (ResUNet.py:565, a leftover of
     ``nn.LSTM``'s tuple): the batch axis is dropped, so the FIRST sample's bottleneck output is broadcast to
@@ -309,8 +315,6 @@ class ResUNetOnFreq2(nn.Module):
         W = 30
         if n_block < 2:
             raise Exception("ERROR::ResUnetOnFreq : n_block({}) < 2".format(n_block))
-        if multi_scale:
-            raise NotImplementedError("multi_scale=True is not restated")
         if bottleneck == "FTGRU":
             raise NotImplementedError("bottleneck FTGRU is not restated")
         kw = dict(activation=activation_layer, norm=norm)
@@ -319,6 +323,16 @@ class ResUNetOnFreq2(nn.Module):
                                          for _ in range(n_block)]
         for i, m in enumerate(self.encoders):
             self.add_module("enc_{}".format(i), m)
+        if multi_scale:
+            self.ms = [nn.Sequential(nn.AvgPool2d((2 ** (n_block + 1 - i), 1), stride=(2 ** (n_block - i), 1),
+                                                  padding=(1, 0))) for i in range(n_block)]
+            for i, m in enumerate(self.ms):
+                self.add_module("ms_{}".format(i), m)
+            self.ms_block = MultiScaleConvBlock(W)
+            self.upsample = [nn.Sequential(nn.Upsample(scale_factor=(s, 1), mode="nearest"), nn.Sigmoid())
+                             for s in [1, 2.2, 4.5, 9, 18.4, 36.8]]
+            for i, m in enumerate(self.upsample):
+                self.add_module("up_{}".format(i), m)
 
         def up(kh):
             return nn.Sequential(ResBlock(W), Decoder(W, W, (kh, 1), (2, 1), (1, 0), output_padding=(1, 0), **kw))
@@ -342,7 +356,10 @@ class ResUNetOnFreq2(nn.Module):
         elif activation == "Identity":
             self.activation_mask = nn.Identity()
         elif activation == "MEA":
-            raise NotImplementedError("the MEA head is not restated")
+            if c_in == 1:
+                raise Exception("ERROR::ResUnetOnFreq::feature must be complex")
+            self.activation_mask = MEA(in_channels=c_out)
+            self.add_module("MEA", self.activation_mask)
         else:
             self.activation_mask = nn.Softplus()
 
@@ -350,9 +367,16 @@ class ResUNetOnFreq2(nn.Module):
         feat = self.layer_input(torch.permute(input, (0, 1, 3, 2)))
         x = torch.permute(feat, (0, 1, 3, 2))
         res = []
-        for enc in self.encoders:
+        ms = None
+        for i, enc in enumerate(self.encoders):
             x = enc(x)
             res.append(x)
+            if self.multi_scale and i < len(self.ms):
+                if ms is None:
+                    ms = self.ms[i](x)
+                else:
+                    ms += self.ms[i](x)
+                ms = self.ms_block(ms)
         y = self.bottleneck(x)[0]                    # [C, F', T]: sample 0 only (see the class docstring)
         for i, rp in enumerate(self.res_paths):
             res[i] = rp(res[i])
@@ -361,6 +385,8 @@ class ResUNetOnFreq2(nn.Module):
         return self.activation_mask(self.out_layer(y))
 
     def output(self, mask, feature):
+        if self.activation == "MEA":
+            return self.last_activation.output(mask, feature)    # no such attribute: AttributeError, as there
         return mask * feature[:, :2]
 
 

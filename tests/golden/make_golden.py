@@ -229,8 +229,9 @@ def main():
         if out is not None:
             save("resunet_onfreq_eval_" + label, out=y_ref.numpy())
 
-    print("ResUNetOnFreq2 as shipped (one input channel, LSTM bottleneck, Softplus and Tanh masks), B=2 F=257 T=16")
-    for label, kw in (("softplus", {}), ("tanh", dict(activation="Tanh", c_in=2))):
+    print("ResUNetOnFreq2 as shipped (LSTM bottleneck; Softplus / Tanh masks, multi-scale branch, MEA head), B=2 F=257 T=16")
+    for label, kw in (("softplus", {}), ("tanh", dict(activation="Tanh", c_in=2)), ("ms", dict(multi_scale=True)),
+                      ("mea", dict(c_in=2, c_out=2, activation="MEA", multi_scale=True))):
         ref = R_res.ResUNetOnFreq2(**kw)
         seeded_fill_(ref, seed=34)
         mine = oracle.ResUNetOnFreq2(**kw)
@@ -240,6 +241,27 @@ def main():
         ref.eval(), mine.eval()
         with torch.no_grad():
             y_ref, y_mine = ref(x), mine(x)
+        if label == "mea":
+            names = ("mag_mask", "real_mask", "imag_mask")
+            for n_, a, b in zip(names, y_ref, y_mine):
+                require_equal(a, b, "ResUNetOnFreq2 MEA " + n_)
+            assert tuple(y_ref[0].shape) == (2, 3, 257, 16) and tuple(y_ref[1].shape) == (2, 257, 16)
+            feat = normal("resunet_onfreq2/feat_mea", (2, 257, 16, 2), seed=34)
+            try:                                                 # UNet_m.custom_atan2 uses numpy without importing it
+                with torch.no_grad():
+                    ref.activation_mask.output(y_ref, feat)
+                mea_output = "ok"
+            except Exception as e:
+                mea_output = type(e).__name__
+            try:
+                ref.output(y_ref, feat)
+                onfreq2_mea_output = "ok"
+            except Exception as e:                               # names an attribute that was never set
+                onfreq2_mea_output = type(e).__name__
+            if out is not None:
+                save("resunet_onfreq2_eval_mea", mag_mask=y_ref[0].numpy(), real_mask=y_ref[1].numpy(),
+                     imag_mask=y_ref[2].numpy())
+            continue
         require_equal(y_ref, y_mine, "ResUNetOnFreq2 eval " + label)
         assert tuple(y_ref.shape) == (2, 1, 257, 16)
         if out is not None:
@@ -431,6 +453,8 @@ def main():
         facts["ResBlock_GELU"] = "ok"
     except Exception as e:  # noqa: BLE001
         facts["ResBlock_GELU"] = type(e).__name__
+    facts["ResUNetOnFreq2_MEA_output"] = onfreq2_mea_output
+    facts["MEA_output"] = mea_output
     # ResUNetOnFreq2's FTGRU bottleneck does not run as shipped
     try:
         net = R_res.ResUNetOnFreq2(bottleneck="FTGRU").eval()

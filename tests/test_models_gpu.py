@@ -138,15 +138,31 @@ def test_resunet_onfreq2_matches_golden_and_oracle(device):
     import oracle
     import unet_amd
     from unet_amd.seeding import normal
-    for label, kw in (("softplus", {}), ("tanh", dict(activation="Tanh", c_in=2))):
+    for label, kw in (("softplus", {}), ("tanh", dict(activation="Tanh", c_in=2)), ("ms", dict(multi_scale=True)),
+                      ("mea", dict(c_in=2, c_out=2, activation="MEA", multi_scale=True))):
         ref = oracle.ResUNetOnFreq2(**kw).eval()
         unet_amd.seeded_fill_(ref, seed=34)
         dev = unet_amd.ResUNetOnFreq2(**kw)
         dev.load_state_dict(ref.state_dict(), strict=True)
+        assert list(dev.state_dict().keys()) == list(ref.state_dict().keys())
         x = normal("resunet_onfreq2/x_" + label, (2, kw.get("c_in", 1), 257, 16), seed=34)
         with torch.no_grad():
             want = ref(x)
             got = dev.eval().to(device)(x.to(device))
+        if label == "mea":
+            gold = load_golden("resunet_onfreq2_eval_mea")
+            assert tuple(got[0].shape) == (2, 3, 257, 16) and tuple(got[1].shape) == (2, 257, 16)
+            for name, g, w in zip(("mag_mask", "real_mask", "imag_mask"), got, want):
+                assert_close(g, w, what="ResUNetOnFreq2 MEA {} HIP vs oracle".format(name))
+                assert_close(g, torch.from_numpy(gold[name]), what="ResUNetOnFreq2 MEA {} HIP vs golden".format(name))
+            # applying the masks: parity unpinned (the reference's MEA.output raises NameError), oracle only
+            feat = normal("resunet_onfreq2/feat_mea", (2, 257, 16, 2), seed=34)
+            with torch.no_grad():
+                assert_close(dev.activation_mask.output(got, feat.to(device)), ref.activation_mask.output(want, feat),
+                             what="MEA.output HIP vs oracle")
+            with pytest.raises(AttributeError):
+                dev.output(got, x.to(device))
+            continue
         assert tuple(got.shape) == (2, 1, 257, 16)
         assert_close(got, want, what="ResUNetOnFreq2 {} HIP vs oracle".format(label))
         assert_close(got, torch.from_numpy(load_golden("resunet_onfreq2_eval_" + label)["out"]),

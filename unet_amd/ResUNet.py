@@ -16,7 +16,7 @@ What runs where:
 import torch
 import torch.nn as nn
 
-from .UNet_m import Decoder, Encoder, ResBlock
+from .UNet_m import Decoder, Encoder, MEA, MultiScaleConvBlock, ResBlock
 from .fused import FusedConv, require_device_tensor
 from .lstm import lstm_forward, supported as lstm_supported
 from .ops import layernorm_f, tanh_mask_mul
@@ -229,9 +229,14 @@ class LSTMBlock(nn.Module):
 
 
 class ResUNetOnFreq2(nn.Module):
-    """Device ``ResUNetOnFreq2`` (ResUNet.py:394-591) for ``multi_scale=False`` and the LSTM bottleneck:
-    ResUNetOnFreq's 30-channel blocks only, an LSTM over the flattened (channel, frequency) features at 7
-    frequency rows, one-channel mask.
+    """Device ``ResUNetOnFreq2`` (ResUNet.py:394-591) with the LSTM bottleneck: ResUNetOnFreq's 30-channel
+    blocks only, an LSTM over the flattened (channel, frequency) features at 7 frequency rows, ``c_out``-channel
+    mask or the MEA head's three masks.
+
+    ``multi_scale=True`` registers the reference's extra modules (``ms_i`` pools, ``ms_block``, ``up_i``) so that
+    its checkpoints load with ``strict=True``.  The reference runs the pools and the block beside the encoders
+    (ResUNet.py:553-560) but nothing downstream reads their result, so the device forward does not launch them:
+    the output is the same with and without the switch.
 
     The reference indexes the bottleneck's output TENSOR with ``[0]`` (ResUNet.py:565), which drops the batch
     axis: the first sample's bottleneck output is what every sample of the batch receives through the
@@ -249,8 +254,6 @@ class ResUNetOnFreq2(nn.Module):
         W = 30
         if n_block < 2:
             raise Exception("ERROR::ResUnetOnFreq : n_block({}) < 2".format(n_block))
-        if multi_scale:
-            raise NotImplementedError("ResUNetOnFreq2: multi_scale=True is not built")
         if bottleneck == "FTGRU":
             raise NotImplementedError("ResUNetOnFreq2: the FTGRU bottleneck fails in the reference's constructor")
         kw = dict(activation=activation_layer, norm=norm)
@@ -259,6 +262,16 @@ class ResUNetOnFreq2(nn.Module):
                                          for _ in range(n_block)]
         for i, m in enumerate(self.encoders):
             self.add_module("enc_{}".format(i), m)
+        if multi_scale:
+            self.ms = [nn.Sequential(nn.AvgPool2d((2 ** (n_block + 1 - i), 1), stride=(2 ** (n_block - i), 1),
+                                                  padding=(1, 0))) for i in range(n_block)]
+            for i, m in enumerate(self.ms):
+                self.add_module("ms_{}".format(i), m)
+            self.ms_block = MultiScaleConvBlock(W)
+            self.upsample = [nn.Sequential(nn.Upsample(scale_factor=(s, 1), mode="nearest"), nn.Sigmoid())
+                             for s in [1, 2.2, 4.5, 9, 18.4, 36.8]]
+            for i, m in enumerate(self.upsample):
+                self.add_module("up_{}".format(i), m)
 
         def up(kh):
             return nn.Sequential(ResBlock(W), Decoder(W, W, (kh, 1), (2, 1), (1, 0), output_padding=(1, 0), **kw))
@@ -282,7 +295,10 @@ class ResUNetOnFreq2(nn.Module):
         elif activation == "Identity":
             self.activation_mask = nn.Identity()
         elif activation == "MEA":
-            raise NotImplementedError("ResUNetOnFreq2: the MEA head is not built")
+            if c_in == 1:
+                raise Exception("ERROR::ResUnetOnFreq::feature must be complex")
+            self.activation_mask = MEA(in_channels=c_out)
+            self.add_module("MEA", self.activation_mask)
         else:
             self.activation_mask = nn.Softplus()
         self._in = self._out = None
@@ -306,9 +322,13 @@ class ResUNetOnFreq2(nn.Module):
                                               fusable))
         head, fused_act = self._out
         m = head(y.float() if y.dtype != torch.float32 else y)
+        if self.activation == "MEA":
+            return tuple(t.to(y.dtype) for t in self.activation_mask(m))
         if not fused_act:
             m = self.activation_mask(m)
         return m.to(y.dtype)
 
     def output(self, mask, feature):
+        if self.activation == "MEA":
+            return self.last_activation.output(mask, feature)   # never set: AttributeError, as ResUNet.py:589
         return mask * feature[:, :2]

@@ -194,3 +194,104 @@ class ResBlock(nn.Module):
             r = resblock_layer(x if i == 0 else r, add if i == 0 else None, f32(dw.weight), f32(dw.bias), f32(pw.weight),
                                f32(pw.bias), st["act_param"], st["scale"], st["shift"], int(_pair(dw.dilation)[1]), i > 0)
         return r
+
+
+class DepthwiseSeparableConv2d(nn.Module):
+    """UNet_m.py:7-31 (parameter names as there; torch's device ops -- only the multi-scale side branch of
+    ``ResUNetOnFreq2`` uses it, and nothing reads that branch's result)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.depthwise = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                   groups=in_channels)
+        self.bn_depth = nn.BatchNorm2d(out_channels)
+        self.pointwise = nn.Conv2d(out_channels, out_channels, kernel_size=1)
+        self.bn_point = nn.BatchNorm2d(out_channels)
+
+    def forward(self, x):
+        require_device_tensor(x, "DepthwiseSeparableConv2d")
+        x = torch.relu(self.bn_depth(self.depthwise(x)))
+        return torch.relu(self.bn_point(self.pointwise(x)))
+
+
+class GlobalChannelLayerNorm(nn.Module):
+    """UNet_m.py:739-763: one mean / variance per sample, per-channel gain and offset."""
+
+    def __init__(self, channel_size):
+        super().__init__()
+        self.channel_size = channel_size
+        self.gamma = nn.Parameter(torch.ones(channel_size))
+        self.beta = nn.Parameter(torch.zeros(channel_size))
+
+    def forward(self, x):
+        require_device_tensor(x, "GlobalChannelLayerNorm")
+        dims = list(range(1, x.dim()))
+        mean = x.mean(dim=dims, keepdim=True)
+        var = torch.pow(x - mean, 2).mean(dim=dims, keepdim=True)
+        normed = (x - mean) / (var + 1e-8).sqrt()
+        return (self.gamma * normed.transpose(1, -1) + self.beta).transpose(1, -1)
+
+
+class MultiScaleConvBlock(nn.Module):
+    """UNet_m.py:771-788."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        c = in_channels
+        self.net = nn.Sequential(nn.Conv2d(c, 2 * c, kernel_size=1), GlobalChannelLayerNorm(2 * c),
+                                 DepthwiseSeparableConv2d(2 * c, 2 * c, kernel_size=1), GlobalChannelLayerNorm(2 * c),
+                                 nn.Conv2d(2 * c, c, kernel_size=1), GlobalChannelLayerNorm(c))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def custom_atan2(y, x):
+    """UNet_m.py:677-686."""
+    pi = torch.tensor([torch.pi], dtype=y.dtype, device=y.device)
+    ans = torch.atan(y / (x + 1e-6))
+    ans += ((y > 0) & (x < 0)) * pi
+    ans -= ((y < 0) & (x < 0)) * pi
+    ans *= 1 - ((y > 0) & (x == 0)) * 1.0
+    ans += ((y > 0) & (x == 0)) * (pi / 2)
+    ans *= 1 - ((y < 0) & (x == 0)) * 1.0
+    ans += ((y < 0) & (x == 0)) * (-pi / 2)
+    return ans
+
+
+class MEA(nn.Module):
+    """Mask estimation and application head (UNet_m.py:691-732).  The three (3,1) convolutions run on the
+    thin-layer kernel; ``output`` is elementwise torch arithmetic on the device (the reference's own
+    ``output`` raises NameError -- numpy is used there without being imported -- so it follows the arithmetic
+    as written)."""
+
+    def __init__(self, in_channels=4, mag_f_dim=3):
+        super().__init__()
+        self.mag_mask = nn.Conv2d(in_channels, mag_f_dim, kernel_size=(3, 1), padding=(1, 0))
+        self.real_mask = nn.Conv2d(in_channels, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.imag_mask = nn.Conv2d(in_channels, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.register_buffer("kernel", torch.eye(mag_f_dim).reshape(mag_f_dim, 1, mag_f_dim, 1))
+        self.mag_f_dim = mag_f_dim
+        self._fused = None
+
+    def forward(self, x):
+        require_device_tensor(x, "MEA")
+        if self._fused is None:
+            object.__setattr__(self, "_fused",
+                               tuple(FusedConv(m) for m in (self.mag_mask, self.real_mask, self.imag_mask)))
+        x = x.float().contiguous()
+        mag, re, im = (f(x) for f in self._fused)
+        return (mag, re.squeeze(1), im.squeeze(1))
+
+    def output(self, mask, feature, eps=1e-9):
+        mag_mask, real_mask, imag_mask = mask[0], mask[1], mask[2]
+        mag = torch.norm(feature, dim=-1)
+        pha = custom_atan2(feature[..., 1], feature[..., 0])
+        h = (self.mag_f_dim - 1) // 2
+        mag = nn.functional.conv2d(nn.functional.pad(mag[:, None], [0, 0, h, h]), self.kernel)
+        mag = (mag * mag_mask.relu()).sum(dim=1)
+        mag_mask = torch.sqrt(torch.clamp(real_mask ** 2 + imag_mask ** 2, eps))
+        pha_mask = custom_atan2(imag_mask + eps, real_mask + eps)
+        real = mag * mag_mask.relu() * torch.cos(pha + pha_mask)
+        imag = mag * mag_mask.relu() * torch.sin(pha + pha_mask)
+        return torch.stack([real, imag], dim=-1)
