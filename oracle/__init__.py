@@ -2,12 +2,13 @@
 
 This package is the parity checker for the HIP path in ``unet_amd``: plain
 ``torch.nn`` CPU modules that restate, layer for layer, what the reference's
-``UNet`` / ``cRFUNet.UNet20`` / ``ResUNet`` / ``DSUNet`` / ``UDSS`` compute.  It is imported
+``UNet`` / ``cRFUNet.UNet20`` / ``ResUNet`` / ``ResUNetOnFreq`` / ``ResUNetOnFreq2`` / ``DSUNet`` /
+``UDSS`` and the wave-to-wave helpers compute.  It is imported
 only by ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 ``bench.py``.  Nothing under ``unet_amd/`` imports it and the product never
 routes a forward through it.
 
-Pinning: ``oracle/check_against_reference.py`` (run in the build container,
+Pinning: ``tests/golden/make_golden.py`` (run in the build container,
 where the reference checkout is importable) loads identical seeded
 state_dicts into the reference modules and into these, and requires
 ``torch.equal`` outputs in eval mode, in train mode and for gradients.  The
