@@ -28,16 +28,48 @@ struct DirectArgs {
     int nkt;        // K tiles
 };
 
-__device__ __forceinline__ float direct_act(float v, int act, float slope) {
-    switch (act) {
-        case UNETMI_ACT_LEAKY:    return v >= 0.f ? v : v * slope;
-        case UNETMI_ACT_RELU:     return fmaxf(v, 0.f);
-        case UNETMI_ACT_SILU:     return v / (1.f + expf(-v));
-        case UNETMI_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
-        case UNETMI_ACT_SIGMOID:  return 1.f / (1.f + expf(-v));
-        case UNETMI_ACT_TANH:     return tanhf(v);
-        case UNETMI_ACT_GELU:     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        default:                  return v;
+// The activation is a template parameter of the epilogue: a run-time switch inlined at each of the KT*RPT
+// results made the <2,16,*> kernels 24,000 instructions long (190 KB of code against a 64 KB instruction
+// cache), and the waves spent their time fetching it.
+template <int ACT>
+__device__ __forceinline__ float direct_act(float v, float slope) {
+    if constexpr (ACT == UNETMI_ACT_LEAKY)         return v >= 0.f ? v : v * slope;
+    else if constexpr (ACT == UNETMI_ACT_RELU)     return fmaxf(v, 0.f);
+    else if constexpr (ACT == UNETMI_ACT_SILU)     return v / (1.f + expf(-v));
+    else if constexpr (ACT == UNETMI_ACT_SOFTPLUS) return v > 20.f ? v : log1pf(expf(v));
+    else if constexpr (ACT == UNETMI_ACT_SIGMOID)  return 1.f / (1.f + expf(-v));
+    else if constexpr (ACT == UNETMI_ACT_TANH)     return tanhf(v);
+    else if constexpr (ACT == UNETMI_ACT_GELU)     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    else                                           return v;
+}
+
+template <int RPT, int KT, bool BF16, int ACT>
+__device__ __forceinline__ void direct_epilogue(const DirectArgs& p, const float (&acc)[KT][RPT], int n, int k0,
+                                                int oh0, int ow) {
+    const size_t OHW = (size_t)p.OH * p.W;
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+        const int co = k0 + kk;
+        if (co >= p.K) continue;
+        const float b = p.bias[co], sc = p.scale[co], sf = p.shift[co];
+        const float slope = p.act_param ? p.act_param[p.act_pc ? co : 0] : 0.f;
+        const float gt = p.gate ? p.gate[(size_t)n * p.K + co] : 1.f;
+        // act_first: act(v) * sc + sf; otherwise act(v * sc + sf).  Written with one call site for the
+        // activation (sc0/sf0 before it, sc1/sf1 after it; the unused pair is the identity 1, 0 -- exact)
+        const float sc0 = p.act_first ? 1.f : sc, sf0 = p.act_first ? 0.f : sf;
+        const float sc1 = p.act_first ? sc : 1.f, sf1 = p.act_first ? sf : 0.f;
+        const size_t chan = ((size_t)n * p.K + co) * OHW;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int oh = oh0 + r;
+            if (oh >= p.OH) continue;
+            float v = acc[kk][r] + b;
+            v = direct_act<ACT>(v * sc0 + sf0, slope) * sc1 + sf1;
+            v *= gt;
+            const size_t o = chan + (size_t)oh * p.W + ow;
+            if (p.residual) v += ld_act<BF16>(p.residual, o);
+            st_act<BF16>(p.out, o, v);
+        }
     }
 }
 
@@ -96,27 +128,13 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectArgs p) {
     }
 
     if (!col_ok) return;
-    const size_t OHW = (size_t)p.OH * p.W;
-#pragma unroll
-    for (int kk = 0; kk < KT; ++kk) {
-        const int co = k0 + kk;
-        if (co >= p.K) continue;
-        const float b = p.bias[co], sc = p.scale[co], sf = p.shift[co];
-        const float slope = p.act_param ? p.act_param[p.act_pc ? co : 0] : 0.f;
-        const float gt = p.gate ? p.gate[(size_t)n * p.K + co] : 1.f;
-        const size_t chan = ((size_t)n * p.K + co) * OHW;
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int oh = oh0 + r;
-            if (oh >= p.OH) continue;
-            float v = acc[kk][r] + b;
-            if (p.act_first) v = direct_act(v, p.act, slope) * sc + sf;
-            else             v = direct_act(v * sc + sf, p.act, slope);
-            v *= gt;
-            const size_t o = chan + (size_t)oh * p.W + ow;
-            if (p.residual) v += ld_act<BF16>(p.residual, o);
-            st_act<BF16>(p.out, o, v);
-        }
+    switch (p.act) {
+#define UNETMI_DIRECT_EPI(A_) case A_: direct_epilogue<RPT, KT, BF16, A_>(p, acc, n, k0, oh0, ow); break;
+        UNETMI_DIRECT_EPI(UNETMI_ACT_LEAKY) UNETMI_DIRECT_EPI(UNETMI_ACT_RELU) UNETMI_DIRECT_EPI(UNETMI_ACT_SILU)
+        UNETMI_DIRECT_EPI(UNETMI_ACT_SOFTPLUS) UNETMI_DIRECT_EPI(UNETMI_ACT_SIGMOID) UNETMI_DIRECT_EPI(UNETMI_ACT_TANH)
+        UNETMI_DIRECT_EPI(UNETMI_ACT_GELU)
+#undef UNETMI_DIRECT_EPI
+        default: direct_epilogue<RPT, KT, BF16, UNETMI_ACT_NONE>(p, acc, n, k0, oh0, ow); break;
     }
 }
 
