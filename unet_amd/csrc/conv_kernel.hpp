@@ -49,17 +49,19 @@ extern unsigned long long* g_stamps;   // [8] accumulated cycles per phase + blo
 #define STAMP(i) do {} while (0)
 #endif
 
-__device__ __forceinline__ float apply_act(float v, int act, float slope) {
-    switch (act) {
-        case UNETMI_ACT_LEAKY:    return v >= 0.f ? v : v * slope;
-        case UNETMI_ACT_RELU:     return fmaxf(v, 0.f);
-        case UNETMI_ACT_SILU:     return v / (1.f + expf(-v));
-        case UNETMI_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
-        case UNETMI_ACT_SIGMOID:  return 1.f / (1.f + expf(-v));
-        case UNETMI_ACT_TANH:     return tanhf(v);
-        case UNETMI_ACT_GELU:     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        default:                  return v;
-    }
+// The activation is a compile-time parameter of the epilogue body (the run-time code picks the body once):
+// a switch inlined at every result makes the kernel tens of thousands of instructions long and scatters
+// the executed path over all of them.
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v, float slope) {
+    if constexpr (ACT == UNETMI_ACT_LEAKY)         return v >= 0.f ? v : v * slope;
+    else if constexpr (ACT == UNETMI_ACT_RELU)     return fmaxf(v, 0.f);
+    else if constexpr (ACT == UNETMI_ACT_SILU)     return v / (1.f + expf(-v));
+    else if constexpr (ACT == UNETMI_ACT_SOFTPLUS) return v > 20.f ? v : log1pf(expf(v));
+    else if constexpr (ACT == UNETMI_ACT_SIGMOID)  return 1.f / (1.f + expf(-v));
+    else if constexpr (ACT == UNETMI_ACT_TANH)     return tanhf(v);
+    else if constexpr (ACT == UNETMI_ACT_GELU)     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    else                                           return v;
 }
 
 // ---------------------------------------------------------------------------------
@@ -258,10 +260,10 @@ __device__ __forceinline__ void group_mfma2(f32x16 (&acc0)[TPG], f32x16 (&acc1)[
 
 // Fused epilogue: bias, BatchNorm affine and activation (either order), gate, residual,
 // store.  Lane = one time column, register = one output channel (MFMA C/D layout).
-template <int NG, int TPG, bool BF16 = false>
-__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NG][TPG], const ConvArgs& p,
-                                              const float* s_par, int n, int cb, int a, int i0, int j0,
-                                              int wm, int wn, int half, int j) {
+template <int NG, int TPG, bool BF16, int ACT>
+__device__ __forceinline__ void conv_epilogue_body(const f32x16 (&acc)[NG][TPG], const ConvArgs& p,
+                                                   const float* s_par, int n, int cb, int a, int i0, int j0,
+                                                   int wm, int wn, int half, int j) {
     const int col_base = wn * 32 + 4 * half;          // this lane's first channel inside the block
     const size_t OHW = (size_t)p.OH * p.OW;
     float e_b[16], e_sc[16], e_sf[16], e_sl[16], e_g[16];
@@ -287,14 +289,29 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NG][TPG], cons
                 if (i >= p.h_nout[a] || !col_ok) continue;
                 const int oh = i * p.h_nphase + a;
                 float v = acc[g][t][r] + e_b[r];
-                if (p.act_first) v = apply_act(v, p.act, e_sl[r]) * e_sc[r] + e_sf[r];
-                else             v = apply_act(v * e_sc[r] + e_sf[r], p.act, e_sl[r]);
+                if (p.act_first) v = apply_act<ACT>(v, e_sl[r]) * e_sc[r] + e_sf[r];
+                else             v = apply_act<ACT>(v * e_sc[r] + e_sf[r], e_sl[r]);
                 v *= e_g[r];
                 const size_t o = chan + (size_t)oh * p.OW + ow;
                 if (p.residual) v += ld_act<BF16>(p.residual, o);
                 if (!ABLATE(4) || v == 123.456f) st_act<BF16>(p.out, o, v);
             }
         }
+    }
+}
+
+template <int NG, int TPG, bool BF16 = false>
+__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NG][TPG], const ConvArgs& p,
+                                              const float* s_par, int n, int cb, int a, int i0, int j0,
+                                              int wm, int wn, int half, int j) {
+    switch (p.act) {
+#define UNETMI_EPI(A_) \
+    case A_: conv_epilogue_body<NG, TPG, BF16, A_>(acc, p, s_par, n, cb, a, i0, j0, wm, wn, half, j); break;
+        UNETMI_EPI(UNETMI_ACT_LEAKY) UNETMI_EPI(UNETMI_ACT_RELU) UNETMI_EPI(UNETMI_ACT_SILU)
+        UNETMI_EPI(UNETMI_ACT_SOFTPLUS) UNETMI_EPI(UNETMI_ACT_SIGMOID) UNETMI_EPI(UNETMI_ACT_TANH)
+        UNETMI_EPI(UNETMI_ACT_GELU)
+#undef UNETMI_EPI
+        default: conv_epilogue_body<NG, TPG, BF16, UNETMI_ACT_NONE>(acc, p, s_par, n, cb, a, i0, j0, wm, wn, half, j);
     }
 }
 
