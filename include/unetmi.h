@@ -181,9 +181,11 @@ int unetmi_pwconv64_fwd(int N, int H, int W, const void* x, const void* x2, cons
  * and reads the pre-projection states back:  hfull[t+1][u][b] = o_t * tanh(c_t);  h_t = W_hr hfull[t+1].
  * hfull is [T+1][H][BP] with slot 0 = the initial state (zeros for the reference's call); BP = batch padded to
  * a multiple of 16 (<= 64; padded columns compute on zeros and are ignored).  sync_ws: 4 * (H/4 + 1) bytes of
- * device scratch (cleared by the call).  H must be 640.  All workgroups have to be resident at once (H/4 <= number of
- * compute units); the call refuses otherwise.  If the device-wide barrier inside ever times out the last slot
- * of hfull is filled with NaN. */
+ * device scratch (cleared by the call).  H must be 640.  All workgroups have to be resident at once (checked with
+ * the runtime's occupancy query); the call refuses otherwise.  If the device-wide barrier inside ever times out
+ * (a workgroup that is not resident after all, e.g. the GPU is shared), every slot of hfull from the step that
+ * timed out on is filled with NaN and the last word of sync_ws, ((uint32_t*)sync_ws)[H/4], is left non-zero
+ * when the launch completes -- the status a caller can fold into its result without a host round trip. */
 int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, void* sync_ws,
                            void* stream);
 

@@ -72,7 +72,7 @@ def hook_outputs(model, names):
     mods = dict(model.named_modules())
     for n in names:
         handles.append(mods[n].register_forward_hook(
-            lambda m, i, o, n=n: store.__setitem__(n, o.detach().clone())))
+            lambda m, i, o, n=n: store.__setitem__(n, (o[0] if isinstance(o, tuple) else o).detach().clone())))
     return store, handles
 
 
@@ -433,6 +433,78 @@ def main():
     except Exception as e:  # noqa: BLE001
         udss_default = type(e).__name__
     print("  UDSS() with its default type_norm:", udss_default)
+
+    # ---------------------------------------------------------------- full-length inputs of the other workloads
+    # (one utterance each; per-layer float64 checksums and fixed samples, as for the UNet at T=509)
+    print("cRFUNet.UNet20 at T=509 (m.T = 509), B=1: per-layer checksums")
+    ref = R_crf.UNet20()
+    seeded_fill_(ref, seed=23)
+    mine = oracle.UNet20()
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    ref.T = mine.T = 509
+    x = uniform("unet20/x509", (1, 14, 257, 509), 0.0, 1.0, seed=23)
+    ref.eval(), mine.eval()
+    store, handles = hook_outputs(ref, layer_names)
+    with torch.no_grad():
+        y_ref, y_mine = ref(x), mine(x)
+    for h in handles:
+        h.remove()
+    require_equal(y_ref, y_mine, "UNet20 eval T=509")
+    assert tuple(y_ref.shape) == (1, 4, 4, 1, 1, 257, 509)
+    if out is not None:
+        arrays = flat_summary("out", y_ref)
+        for n in layer_names:
+            arrays.update(flat_summary(n, store[n]))
+        save("unet20_full_eval_T509", **arrays)
+
+    print("ResUNet at T=501, B=1: per-layer checksums (501 dependent LSTM steps)")
+    ref = R_res.ResUNet()
+    seeded_fill_(ref, seed=36)
+    mine = oracle.ResUNet()
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    x = normal("resunet/x501", (1, 4, 257, 501), seed=36)
+    ref.eval(), mine.eval()
+    res_names = ["enc_{}".format(i) for i in range(8)] + ["bottleneck"] + ["dec_{}".format(i) for i in range(8)]
+    store, handles = hook_outputs(ref, res_names)
+    with torch.no_grad():
+        y_ref, y_mine = ref(x), mine(x)
+    for h in handles:
+        h.remove()
+    require_equal(y_ref, y_mine, "ResUNet eval T=501")
+    assert tuple(y_ref.shape) == (1, 2, 257, 501)
+    if out is not None:
+        arrays = flat_summary("out", y_ref)
+        for n in res_names:
+            arrays.update(flat_summary(n, store[n]))
+        save("resunet_full_eval_T501", **arrays)
+
+    print("DSUNet at T=512, B=1: per-layer checksums")
+    ref = R_ds.DSUNet(arch)
+    seeded_fill_(ref, seed=44)
+    mine = oracle.DSUNet(arch)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    sf5 = normal("dsunet/sf512", (1, 8, 257, 512), seed=44)
+    SV5 = normal("dsunet/SV512", (1, 4, 514), seed=44)
+    ang5 = uniform("dsunet/theta512", (1,), 0.0, 2 * np.pi, seed=44)
+    theta5 = torch.stack([torch.sin(ang5), torch.cos(ang5)], dim=1)
+    ref.eval(), mine.eval()
+    ds_names = ["encoder{}".format(i) for i in range(10)] + ["decoder{}".format(i) for i in range(10)]
+    gate_names = ["attractEncoder_{}".format(i) for i in range(10)]
+    store, handles = hook_outputs(ref, ds_names + gate_names)
+    with torch.no_grad():
+        y_ref, y_mine = ref(sf5, SV5, theta5), mine(sf5, SV5, theta5)
+    for h in handles:
+        h.remove()
+    require_equal(y_ref, y_mine, "DSUNet eval T=512")
+    assert tuple(y_ref.shape) == (1, 257, 512)
+    if out is not None:
+        arrays = flat_summary("out", y_ref)
+        for i, n in enumerate(ds_names):
+            t = store[n]
+            if i < 10:          # an encoder's output as the next layer sees it: times its gate (DSUNet.py:599-602)
+                t = store[gate_names[i]][:, :, None, None] * t
+            arrays.update(flat_summary(n, t))
+        save("dsunet_full_eval_T512", **arrays)
 
     # ------------------------------------------------- negative behaviours (kept as facts)
     print("negative behaviours of the reference")

@@ -1,0 +1,153 @@
+"""Full-length parity of the other benchmark workloads on the device: cRFUNet.UNet20 at T=509, ResUNet at T=501
+(501 dependent steps through the recurrence kernel), DSUNet at T=512, and the projected LSTM alone at batch 32.
+
+Each model runs a batch of two: sample 0 is the golden input, so every hooked layer's output for it is checked
+against the per-layer checksums and samples the reference produced (tests/golden/make_golden.py); sample 1 is
+checked against the oracle run on it alone.  fp32, rel-err 1e-4 (cRFUNet.py:279-324, ResUNet.py:161-220,
+DSUNet.py:582-628)."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, load_golden, rel_err, sample_index
+
+pytestmark = pytest.mark.gpu
+
+
+def check_layers(golden, tensors, tol=1e-4):
+    """tensors: golden name -> sample-0 tensor of that layer (cpu).  Samples within tol of the layer's scale
+    (the larger of its largest sample and its rms), sum and sum of squares within tol."""
+    worst = 0.0
+    for n, t in tensors.items():
+        if t.is_complex():
+            t = torch.view_as_real(t)
+        t = t.reshape(-1).double().numpy()
+        assert t.size == int(golden[n + "_numel"]), n
+        want = golden[n + "_samples"].astype(np.float64)
+        have = t[sample_index(t.size)]
+        scale = np.sqrt(float(golden[n + "_sumsq"]) / t.size)
+        err = np.abs(have - want).max() / max(np.abs(want).max(), scale)
+        worst = max(worst, err)
+        assert err <= tol, "{}: sample error {:.3e}".format(n, err)
+        assert abs((t * t).sum() - float(golden[n + "_sumsq"])) <= tol * float(golden[n + "_sumsq"]), n
+        assert abs(t.sum() - float(golden[n + "_sum"])) <= tol * scale * t.size, n
+    return worst
+
+
+def hook_sample0(model, names):
+    store, mods = {}, dict(model.named_modules())
+    handles = [mods[dev_name].register_forward_hook(
+        lambda m, i, o, g=gold_name: store.__setitem__(g, o[0].detach().cpu())) for dev_name, gold_name in names]
+    return store, handles
+
+
+def test_unet20_full_length(device):
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import uniform
+    ref = oracle.UNet20().eval()
+    unet_amd.seeded_fill_(ref, seed=23)
+    dev = unet_amd.UNet20()
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    ref.T = dev.T = 509
+    dev.eval().to(device)
+    x = torch.cat([uniform("unet20/x509", (1, 14, 257, 509), 0.0, 1.0, seed=23),
+                   uniform("unet20/x509b", (1, 14, 257, 509), 0.0, 1.0, seed=24)])
+    names = ["encoder_{}".format(i) for i in range(10)] + ["decoder_{}".format(i) for i in range(10)]
+    store, handles = hook_sample0(dev, [(n, n) for n in names])
+    with torch.no_grad():
+        got = dev(x.to(device)).cpu()
+        want1 = ref(x[1:2])
+    for h in handles:
+        h.remove()
+    assert got.dtype == torch.complex64 and tuple(got.shape) == (2, 4, 4, 1, 1, 257, 509)
+    store["out"] = got[0]
+    worst = check_layers(load_golden("unet20_full_eval_T509"), store)
+    e = assert_close(got[1:2], want1, what="UNet20 T=509, sample 1 vs oracle")
+    print("UNet20 T=509: worst layer sample error {:.2e}, output rel-err vs oracle {:.2e}".format(worst, e))
+
+
+def test_resunet_full_length(device):
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    ref = oracle.ResUNet().eval()
+    unet_amd.seeded_fill_(ref, seed=36)
+    dev = unet_amd.ResUNet()
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    x = torch.cat([normal("resunet/x501", (1, 4, 257, 501), seed=36), normal("resunet/x501b", (1, 4, 257, 501), seed=37)])
+    # decoders 2..6 are Sequential(ResBlock, Decoder) run member by member: hook the member that ends them
+    names = [("enc_{}".format(i),) * 2 for i in range(8)] + [("dec_0", "dec_0"), ("dec_1", "dec_1")] + \
+            [("dec_{}.1".format(i), "dec_{}".format(i)) for i in range(2, 7)] + [("dec_7", "dec_7")]
+    store, handles = hook_sample0(dev, names)
+    with torch.no_grad():
+        got = dev(x.to(device)).cpu()
+        want1 = ref(x[1:2])
+    for h in handles:
+        h.remove()
+    assert tuple(got.shape) == (2, 2, 257, 501) and not torch.isnan(got).any()
+    store["out"] = got[0]
+    worst = check_layers(load_golden("resunet_full_eval_T501"), store)
+    e = assert_close(got[1:2], want1, what="ResUNet T=501, sample 1 vs oracle")
+    # the last frames carry the whole 501-step recurrence
+    e_last = rel_err(got[1:2, :, :, -8:], want1[:, :, :, -8:])
+    print("ResUNet T=501: worst layer sample error {:.2e}, output rel-err {:.2e} (last 8 frames {:.2e})".format(
+        worst, e, e_last))
+    assert e_last <= 1e-4
+
+
+def test_dsunet_full_length(device):
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.DSUNet(oracle.dsunet_architecture(45, 8)).eval()
+    unet_amd.seeded_fill_(ref, seed=44)
+    dev = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8))
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    sf = torch.cat([normal("dsunet/sf512", (1, 8, 257, 512), seed=44), normal("dsunet/sf512b", (1, 8, 257, 512), seed=45)])
+    SV = torch.cat([normal("dsunet/SV512", (1, 4, 514), seed=44), normal("dsunet/SV512b", (1, 4, 514), seed=45)])
+    ang = torch.cat([uniform("dsunet/theta512", (1,), 0.0, 2 * np.pi, seed=44),
+                     uniform("dsunet/theta512b", (1,), 0.0, 2 * np.pi, seed=45)])
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    # an encoder's device output already carries its gate (fused in the epilogue); the golden holds it that way
+    names = ["encoder{}".format(i) for i in range(10)] + ["decoder{}".format(i) for i in range(10)]
+    store, handles = hook_sample0(dev, [(n, n) for n in names])
+    with torch.no_grad():
+        got = dev(sf.to(device), SV.to(device), theta.to(device)).cpu()
+        want1 = ref(sf[1:2], SV[1:2], theta[1:2])
+    for h in handles:
+        h.remove()
+    assert got.dtype == torch.complex64 and tuple(got.shape) == (2, 257, 512)
+    store["out"] = got[0]
+    worst = check_layers(load_golden("dsunet_full_eval_T512"), store)
+    e = assert_close(got[1:2], want1, what="DSUNet T=512, sample 1 vs oracle")
+    print("DSUNet T=512: worst layer sample error {:.2e}, output rel-err vs oracle {:.2e}".format(worst, e))
+
+
+def test_projected_lstm_full_length(device):
+    """lstm_forward at the benchmark's shape (batch 32, 501 steps, three layers) against torch's CPU LSTM; the
+    error is reported for the whole sequence and for the last step, where 501 steps of rounding have accumulated."""
+    import copy
+    import unet_amd
+    from unet_amd.lstm import lstm_forward
+    from unet_amd.seeding import normal
+    ref = torch.nn.LSTM(384, 640, 3, batch_first=True, proj_size=384)
+    holder = torch.nn.Module()
+    holder.lstm = ref
+    unet_amd.seeded_fill_(holder, seed=72)
+    x = normal("lstm/x501", (32, 501, 384), seed=72)
+    with torch.no_grad():
+        want = ref(x)[0]
+    dev = copy.deepcopy(ref).to(device)
+    got = lstm_forward(dev, x.to(device), {}).cpu()
+    assert not torch.isnan(got).any(), "the recurrence kernel aborted"
+    e_all = rel_err(got, want)
+    e_last = rel_err(got[:, -1], want[:, -1])
+    print("projected LSTM B=32 T=501: rel-err {:.2e} over the sequence, {:.2e} at step 501".format(e_all, e_last))
+    assert e_all <= 1e-4 and e_last <= 1e-4
+    # a second run gives the same bits: no read of a state row that is still in flight
+    again = lstm_forward(dev, x.to(device), {}).cpu()
+    assert torch.equal(got, again)

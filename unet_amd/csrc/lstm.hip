@@ -12,7 +12,8 @@
 // registers), the partial sums meet in LDS, 4 x batch threads apply the gate nonlinearities and write the
 // new hfull rows, and the H/4 workgroups meet at a device-wide barrier (per-workgroup flag words, coherent
 // loads and stores).  The barrier spin is bounded: after the limit a workgroup raises an abort flag that
-// releases every other workgroup, and the output is poisoned with NaN, so the grid always drains.
+// releases every other workgroup, every state row from the aborted step on is NaN and the flag stays raised in
+// sync[nwg] for the caller, so the grid always drains and a failure cannot pass for a result.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -47,7 +48,12 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // write-back / invalidate is needed, only that the stores have completed before the flag is raised.
 // Returns false when aborted (bounded spin).
 __device__ __forceinline__ bool grid_barrier(unsigned* flags, int nwg, unsigned step, int* s_flag) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this thread's stores have completed
+    // Every thread waits until its own state-row stores have been acknowledged by the memory side (they are
+    // write-through, device-coherent stores) BEFORE the workgroup barrier, so that the flag store that follows
+    // the barrier cannot overtake them on another memory channel.  A workgroup-scope fence alone does not wait
+    // for outstanding vector stores on this target.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     const int tid = threadIdx.x;
     if (tid < 64) {
@@ -93,8 +99,8 @@ __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs 
     float c = 0.f;
     __syncthreads();
 
-    bool alive = true;
-    for (int t = 0; t < a.T && alive; ++t) {
+    int t = 0;
+    for (; t < a.T; ++t) {
         const float* hprev = a.hfull + (size_t)t * kLstmH * BP;
         // ---- this wave's quarter of the K range ----
         f32x4 acc[NCT];
@@ -137,10 +143,13 @@ __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs 
             __hip_atomic_store(&a.hfull[((size_t)(t + 1) * kLstmH + u0 + cu) * BP + cb], og * tanhf(c), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
-        alive = grid_barrier(a.sync, a.nwg, (unsigned)(t + 1), &s_flag);
+        if (!grid_barrier(a.sync, a.nwg, (unsigned)(t + 1), &s_flag)) break;
     }
-    if (!alive && cell_thread)        // poison the result so an aborted run cannot pass for a finished one
-        a.hfull[((size_t)a.T * kLstmH + u0 + cu) * BP + cb] = __builtin_nanf("");
+    // Aborted at step t: every state row from that step on is NaN, so nothing computed from a state that was
+    // never exchanged can pass for a result (sync[nwg] stays raised for the caller as well).
+    if (t < a.T && cell_thread)
+        for (int tt = t + 1; tt <= a.T; ++tt)
+            a.hfull[((size_t)tt * kLstmH + u0 + cu) * BP + cb] = __builtin_nanf("");
 }
 
 }  // namespace unetmi
@@ -160,8 +169,19 @@ extern "C" int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, c
     LstmArgs a{};
     a.wrec = wrec; a.gx = gx; a.hfull = hfull; a.sync = static_cast<unsigned*>(sync_ws);
     a.T = T; a.BP = BP; a.nwg = H / 4;
-    // the device-wide barrier needs every workgroup resident at once: one per compute unit
-    if (a.nwg > cus) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: fewer compute units than workgroups");
+    // the device-wide barrier needs every workgroup resident at once: ask the runtime how many workgroups of this
+    // kernel (its registers and LDS) one compute unit holds, instead of assuming one
+    int per_cu = 0;
+    hipError_t oe;
+    switch (BP / 16) {
+        case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<1>, 256, 0); break;
+        case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<2>, 256, 0); break;
+        case 3: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<3>, 256, 0); break;
+        default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<4>, 256, 0); break;
+    }
+    if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence occupancy query: ") + hipGetErrorString(oe));
+    if ((long long)per_cu * cus < a.nwg)
+        return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: the device cannot hold all workgroups at once");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(sync_ws, 0, (size_t)(a.nwg + 1) * sizeof(unsigned), s);
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence memset: ") + hipGetErrorString(e));

@@ -50,6 +50,7 @@ def lstm_forward(lstm, x, cache):
         seq = torch.zeros((T, x.shape[2], BP), dtype=torch.float32, device=dev)      # [T, in, BP]
         seq[:, :, :B] = x.permute(1, 2, 0)
         sync = torch.empty(lstm.hidden_size // 4 + 1, dtype=torch.int32, device=dev)
+        aborted = torch.zeros((), dtype=torch.int32, device=dev)
         for layer in range(lstm.num_layers):
             w_ih = getattr(lstm, "weight_ih_l{}".format(layer)).detach().float()
             w_hr = getattr(lstm, "weight_hr_l{}".format(layer)).detach().float()
@@ -62,5 +63,9 @@ def lstm_forward(lstm, x, cache):
                 check(_lib.lib.unetmi_lstm_recurrence(T, BP, H, wrec.data_ptr(), gx.data_ptr(), hfull.data_ptr(),
                                                       sync.data_ptr(), torch.cuda.current_stream().cuda_stream),
                       "unetmi_lstm_recurrence")
+            aborted = aborted | sync[-1]                                              # the kernel's status word, kept on the device
             seq = torch.matmul(w_hr, hfull[1:])                                       # [T, proj, BP] = next layer's input
-        return seq[:, :, :B].permute(2, 0, 1).contiguous()
+        out = seq[:, :, :B].permute(2, 0, 1).contiguous()
+        # a recurrence whose device-wide barrier timed out (GPU shared with other work) must not pass for a
+        # result: the whole output becomes NaN, without a host round trip
+        return torch.where(aborted != 0, torch.full_like(out, float("nan")), out)
