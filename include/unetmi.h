@@ -268,6 +268,18 @@ size_t unetmi_bn_workspace_bytes(int N, int C, int HW);
 int unetmi_bn_train_stats(int N, int C, int HW, const float* z, float eps, float momentum, float* running_mean,
                           float* running_var, float* mean, float* invstd, void* ws, size_t ws_bytes, void* stream);
 
+/* unetmi_bn_train_stats for callers that cannot allocate device memory or bring a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.
+ * Same arguments and results as unetmi_bn_train_stats without ws / ws_bytes: the per-block partial sums go to a
+ * 256 KiB array in the library's own device image (one copy per GPU, held until the process ends).  Limit:
+ * C * splits * 16 bytes <= 256 KiB, where splits is the number of blocks a channel's N*HW values are divided into
+ * (about 4096 / C, at most 1024): every layer of the reference's networks fits (C <= 384 at any size); larger
+ * requests return UNETMI_E_UNSUPPORTED.  Calls on the same GPU share the array: two calls that overlap in time on
+ * one GPU (different streams or threads) race; calls on one stream are ordered and safe.  Calls no hipMalloc,
+ * hipFree or any allocating routine. */
+int unetmi_bn_train_stats_static(int N, int C, int HW, const float* z, float eps, float momentum,
+                                 float* running_mean, float* running_var, float* mean, float* invstd, void* stream);
+
 /* out = act((z - mean) * invstd * gamma + beta), act = UNETMI_ACT_* with one shared parameter
  * (act_param[0], LeakyReLU slope) or none. */
 int unetmi_bn_act_fwd(int N, int C, int HW, const float* z, const float* mean, const float* invstd,

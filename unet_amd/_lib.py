@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "unetmi_crf_apply",
     "unetmi_bn_workspace_bytes",
     "unetmi_bn_train_stats",
+    "unetmi_bn_train_stats_static",
     "unetmi_bn_act_fwd",
     "unetmi_bn_act_bwd",
     "unetmi_conv2d_wgrad_workspace_bytes",
@@ -90,6 +91,8 @@ def _load():
     lib.unetmi_bn_workspace_bytes.argtypes = [ci] * 3
     lib.unetmi_bn_workspace_bytes.restype = sz
     lib.unetmi_bn_train_stats.argtypes = [ci] * 3 + [fp, cf, cf] + [fp] * 4 + [vp, sz, vp]
+    lib.unetmi_bn_train_stats_static.argtypes = [ci] * 3 + [fp, cf, cf] + [fp] * 4 + [vp]
+    lib.unetmi_bn_train_stats_static.restype = ctypes.c_int
     lib.unetmi_bn_act_fwd.argtypes = [ci] * 3 + [fp] * 5 + [ci, fp, fp, vp]
     lib.unetmi_bn_act_bwd.argtypes = [ci] * 3 + [fp, ll] + [fp] * 5 + [ci, fp, ci] + [fp] * 4 + [vp, sz, vp]
     lib.unetmi_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <mutex>
 #include <string>
 
 #include "../../include/unetmi.h"
@@ -253,6 +254,32 @@ static int check_sizes(const char* what, int N, int C, int HW) {
     return UNETMI_OK;
 }
 
+// Scratch of the entry point that must not allocate: the per-block partial sums live in this file-scope device
+// array (every GPU the library runs on holds its own copy until the process ends).  In host code the array's name
+// is only a stand-in for the symbol; its device address is looked up once per device and kept.
+constexpr size_t kStaticScratchDoubles = 32768;                   // 256 KiB: C * splits * 2 partial sums
+static __device__ __align__(256) double scratch[kStaticScratchDoubles];
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static double* g_scratch_ptr[kMaxDevices];                         // guarded by g_scratch_mutex
+
+static int static_scratch_of_current_device(double** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("static scratch: hipGetDevice: ") + hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return api_fail(UNETMI_E_UNSUPPORTED, "static scratch: device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return api_fail(UNETMI_E_HIP, std::string("static scratch: hipGetSymbolAddress: ") + hipGetErrorString(e));
+        g_scratch_ptr[dev] = static_cast<double*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return UNETMI_OK;
+}
+
 static int launched(const char* what) {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
@@ -283,6 +310,30 @@ int unetmi_bn_train_stats(int N, int C, int HW, const float* z, float eps, float
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(C), dim3(64), 0, s, a.ws, a.S, (long long)N * HW, eps, momentum,
                        running_mean, running_var, mean, invstd);
     return launched("bn_train_stats");
+}
+
+int unetmi_bn_train_stats_static(int N, int C, int HW, const float* z, float eps, float momentum,
+                                 float* running_mean, float* running_var, float* mean, float* invstd, void* stream) {
+    if (int rc = check_sizes("bn_train_stats_static", N, C, HW)) return rc;
+    if (N == 0) return api_fail(UNETMI_E_BAD_ARG, "bn_train_stats_static: batch statistics of an empty batch");
+    if (!z || !mean || !invstd) return api_fail(UNETMI_E_BAD_ARG, "bn_train_stats_static: null pointer");
+    BnArgs a{};
+    a.z = z; a.N = N; a.C = C; a.HW = HW;
+    a.S = splits_for(N, C, HW, &a.chunk);
+    if ((size_t)C * a.S * 2 > kStaticScratchDoubles)
+        return api_fail(UNETMI_E_UNSUPPORTED,
+                        "bn_train_stats_static: " + std::to_string((size_t)C * a.S * 2 * sizeof(double)) +
+                            " bytes of partial sums exceed the " + std::to_string(kStaticScratchDoubles * sizeof(double)) +
+                            "-byte static scratch; use unetmi_bn_train_stats with a workspace");
+    double* ws = nullptr;
+    if (int rc = static_scratch_of_current_device(&ws)) return rc;
+    a.ws = ws;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // every partial the finish kernel reads is written by the reduce kernel of this call: nothing to clear
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(a.S, C), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(C), dim3(64), 0, s, a.ws, a.S, (long long)N * HW, eps, momentum,
+                       running_mean, running_var, mean, invstd);
+    return launched("bn_train_stats_static");
 }
 
 int unetmi_bn_act_fwd(int N, int C, int HW, const float* z, const float* mean, const float* invstd,
