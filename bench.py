@@ -2,8 +2,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (N > 1: launched by torch.distributed.run, one rank per
-GPU over RCCL).  A step = one forward of the "UNet default config" (the 10+10
+One process per GPU.  With N > 1 and no WORLD_SIZE in the environment this
+process only starts ``python -m torch.distributed.run --nproc-per-node N`` on
+itself as a child (it has not touched the GPU) and exits with the child's
+code; under torch.distributed.run each rank binds to its GPU and joins an
+RCCL process group.  A step = one forward of the "UNet default config" (the 10+10
 layer table of cRFUNet.py:192-218 with c_in=2 and a 1-channel last decoder
 around UNet.py's shell) over a batch of 64 synthetic 4-second utterances per
 GPU: complex STFT planes N(0,1), n_fft 512 / hop 128 -> F=257, T=501, zero
@@ -11,7 +14,11 @@ padded to T=509 (the table only accepts T = 13 mod 16); an utterance counts
 4.0 s.  Inputs are resident in HBM before the timed region.  The batch shards
 over ranks with no collective in the data path (eval-mode forward has no
 cross-sample op); a barrier brackets the timed region and the maximum time
-over ranks is used.
+over ranks is used.  Utterance i of the global batch is generated from seed
+1234 + i and rank r takes the rows unet_amd.sharding.shard_batch gives it:
+by default the global batch is 64 x N (weak scaling), ``--global-batch G``
+fixes it (strong scaling).  The line carries ``ranks_seen`` (an all-reduce of
+ones over the process group, on the data device) and every rank's own time.
 
 Rank 0 prints ONE JSON line.  "roofline" is for the dominant kernel
 (the conv_dma_kernel instantiation with the largest share of the step), from HIP events recorded on the launch stream around each of its
@@ -22,6 +29,7 @@ ops) on a batch of 4 on the host cores, rank 0 at N=1 only.
 """
 
 import argparse
+import importlib.util
 import json
 import os
 import sys
@@ -39,10 +47,37 @@ F_BINS, T_FRAMES, T_PADDED = 257, 501, 509
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 
 
+def load_launcher():
+    """unet_amd/launch.py by path: importing the package would load the HIP library, which the launching parent
+    of a multi-rank run must not do."""
+    spec = importlib.util.spec_from_file_location("unetmi_launch", os.path.join(ROOT, "unet_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def synthetic_batch(batch, seed):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn((batch, 2, F_BINS, T_FRAMES), generator=g)
     return torch.nn.functional.pad(x, (0, T_PADDED - T_FRAMES)).contiguous()
+
+
+def synthetic_utterances(lo, hi):
+    """Rows [lo, hi) of the global batch: utterance i is a function of i alone, so any sharding of the batch
+    sees the same utterances."""
+    if hi <= lo:
+        return torch.zeros((0, 2, F_BINS, T_PADDED))
+    return torch.cat([synthetic_batch(1, 1234 + i) for i in range(lo, hi)])
+
+
+def shard_of(args, per_gpu, ranks):
+    """(global batch, lo, hi, "weak" | "strong") for this rank."""
+    spec = importlib.util.spec_from_file_location("unetmi_sharding", os.path.join(ROOT, "unet_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    total = args.global_batch if args.global_batch else per_gpu * ranks.world
+    lo, hi = sharding.shard_batch(total, ranks.rank, ranks.world)
+    return total, lo, hi, ("strong" if args.global_batch else "weak")
 
 
 def conv_macs(d):
@@ -132,20 +167,22 @@ def cpu_train_baseline(threads):
                        "after 1 warm-up, torch {} CPU autograd".format(torch.__version__))
 
 
-def run_train(args, rank, world, dev):
+def run_train(args, ranks):
     """Data-parallel training step of the same UNet: train-mode forward, MSE to a U(0,1) target mask,
     backward, ONE all-reduce of the flat gradient bucket over RCCL, Adam.  8 utterances per GPU."""
     import unet_amd
     from unet_amd.train import FlatAdam, train_step
-    if world > 1:
-        import torch.distributed as dist
+    rank, world, dev = ranks.rank, ranks.world, ranks.device
     net = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=32))
     unet_amd.seeded_fill_(net, seed=0)
     net.train().to(dev)
     opt = FlatAdam(net.parameters(), lr=1e-3)
-    x = synthetic_batch(TRAIN_PER_GPU_BATCH, 1234 + rank).to(dev)
-    target = torch.rand((TRAIN_PER_GPU_BATCH, 1, F_BINS, T_PADDED),
-                        generator=torch.Generator().manual_seed(99 + rank)).to(dev)
+    total, lo, hi, scaling = shard_of(args, TRAIN_PER_GPU_BATCH, ranks)
+    if hi - lo < 1:
+        raise SystemExit("train step: rank {} has no utterance (global batch {})".format(rank, total))
+    x = synthetic_utterances(lo, hi).to(dev)
+    target = torch.cat([torch.rand((1, 1, F_BINS, T_PADDED), generator=torch.Generator().manual_seed(99 + i))
+                        for i in range(lo, hi)]).to(dev)
     verbose = os.environ.get("UNETMI_BENCH_VERBOSE") == "1"
     for i in range(args.warmup):
         loss = train_step(net, opt, x, target)
@@ -153,34 +190,33 @@ def run_train(args, rank, world, dev):
             torch.cuda.synchronize()
             print("[rank {}] warm-up step {} loss {:.5f}".format(rank, i, loss.item()), file=sys.stderr, flush=True)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    ranks.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = train_step(net, opt, x, target)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    ranks.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    per_rank = ranks.gather_float(elapsed)
+    elapsed = max(per_rank)
+    seen = ranks.ranks_seen()
     if rank != 0:
         return
-    flops = 3 * 64.34e9 * TRAIN_PER_GPU_BATCH * args.steps        # fwd + input-gradient + weight-gradient convs
+    flops = 3 * 64.34e9 * (hi - lo) * args.steps        # fwd + input-gradient + weight-gradient convs, this GPU
     achieved = flops / elapsed / 1e12
     result = {
         "metric": "audio-seconds trained/sec (whole node), UNet train step fp32",
-        "value": world * TRAIN_PER_GPU_BATCH * AUDIO_SECONDS * args.steps / elapsed, "unit": "audio-s/s",
+        "value": total * AUDIO_SECONDS * args.steps / elapsed, "unit": "audio-s/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "UNet default config, train() step: forward with batch statistics, "
                                "mean((mask-target)^2), backward, all-reduce(mean) of one flat gradient bucket, "
                                "Adam(1e-3); batch 8 x [2,257,509] fp32 per GPU",
-                   "per_gpu_batch": TRAIN_PER_GPU_BATCH, "global_batch": world * TRAIN_PER_GPU_BATCH,
+                   "per_gpu_batch": hi - lo, "global_batch": total,
                    "gflop_per_utterance": 3 * 64.34, "parallelism": "data-parallel x{}".format(world),
                    "final_loss": float(loss.item())},
+        "ranks_seen": seen, "backend": ranks.backend,
+        "per_rank_ms": [1e3 * t / args.steps for t in per_rank],
         "roofline": {"bound": "mfma", "kernel": "whole step (conv fwd + dgrad + wgrad)", "achieved": achieved,
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                      "traffic": None},
@@ -199,32 +235,43 @@ def main():
     ap.add_argument("--layers", action="store_true", help="per-layer times of the last step on stderr")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward: the headline metric (default); train: the data-parallel training step")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="fixed global batch sharded over the ranks (strong scaling); default 64 per GPU (8 for train)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="host-side check of the launch, sharding and reductions: no GPU, no compute, no measurement")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus {} but WORLD_SIZE={}: launch with torch.distributed.run "
-                         "--nproc-per-node {}".format(args.gpus, world, args.gpus))
-    # Rehearsal knobs for a box with fewer GPUs than ranks (never used by a real run): all ranks on
-    # device 0 and the gloo backend instead of RCCL, which refuses two ranks on one GPU.
-    rehearsal = os.environ.get("UNETMI_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+    launcher = load_launcher()
+    if launcher.needs_self_launch(args.gpus):
+        # started as one process: the ranks are children of this one, which has not touched the GPU
+        sys.exit(launcher.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+    if os.environ.get("UNETMI_BENCH_STALL_DUMP"):
+        # diagnosis aid: after that many seconds every rank prints its Python stacks and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["UNETMI_BENCH_STALL_DUMP"]), exit=True)
+    ranks = launcher.init_ranks(args.gpus, use_gpu=not args.plumbing_only)
+    rank, world, dev = ranks.rank, ranks.world, ranks.device
+
+    if args.plumbing_only:
+        total, lo, hi, scaling = shard_of(args, PER_GPU_BATCH, ranks)
+        ranks.barrier()
+        t0 = time.perf_counter()
+        ranks.barrier()
+        per_rank = ranks.gather_float(time.perf_counter() - t0)
+        sizes = ranks.gather_float(hi - lo)
+        seen = ranks.ranks_seen()
+        if rank == 0:
+            print(json.dumps({"plumbing_only": True, "value": None, "n_gpus": world, "scaling": scaling,
+                              "ranks_seen": seen, "backend": ranks.backend, "global_batch": total,
+                              "per_rank_batch": [int(v) for v in sizes], "per_rank_ms": [1e3 * t for t in per_rank]}),
+                  flush=True)
+        ranks.shutdown()
+        return
 
     if args.mode == "train":
-        run_train(args, rank, world, dev)
-        if world > 1:
-            dist.destroy_process_group()
+        run_train(args, ranks)
+        ranks.shutdown()
         return
 
     import unet_amd
@@ -233,11 +280,9 @@ def main():
     net = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=32))
     unet_amd.seeded_fill_(net, seed=0)       # every rank regenerates the same weights
     net.eval().to(dev)
-    x = synthetic_batch(PER_GPU_BATCH, 1234 + rank).to(dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    total, lo, hi, scaling = shard_of(args, PER_GPU_BATCH, ranks)
+    x = synthetic_utterances(lo, hi).to(dev)
+    barrier = ranks.barrier
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -259,12 +304,11 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         ops.set_launch_observer(None)
-    assert tuple(y.shape) == (PER_GPU_BATCH, 1, F_BINS, T_PADDED)
+    assert tuple(y.shape) == (hi - lo, 1, F_BINS, T_PADDED)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    per_rank = ranks.gather_float(elapsed)
+    elapsed = max(per_rank)
+    seen = ranks.ranks_seen()
 
     if rank == 0 and args.layers:
         per_step = len(records) // args.steps
@@ -284,16 +328,18 @@ def main():
         achieved = flops / secs / 1e12
         result = {
             "metric": "audio-seconds processed/sec (whole node), UNet fwd fp32",
-            "value": world * PER_GPU_BATCH * AUDIO_SECONDS * args.steps / elapsed,
+            "value": total * AUDIO_SECONDS * args.steps / elapsed,
             "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "ranks_seen": seen, "backend": ranks.backend,
+            "per_rank_ms": [1e3 * t / args.steps for t in per_rank],
             "config": {"workload": "UNet default config (cRFUNet.UNet20 layer table, c_in=2, c_last=1) "
                                    "eval forward, batch 64 x [2,257,509] fp32 per GPU "
                                    "(4 s @ 16 kHz, n_fft 512, hop 128, T 501 zero-padded to 509)",
-                       "per_gpu_batch": PER_GPU_BATCH, "global_batch": world * PER_GPU_BATCH,
+                       "per_gpu_batch": hi - lo, "global_batch": total,
                        "gflop_per_utterance": 64.34, "parallelism": "batch-sharded x{}".format(world)},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -308,8 +354,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(torch.get_num_threads())
         print(json.dumps(result), flush=True)
 
-    if world > 1:
-        dist.destroy_process_group()
+    ranks.shutdown()
 
 
 if __name__ == "__main__":

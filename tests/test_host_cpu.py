@@ -250,3 +250,42 @@ def test_b16_weight_image_layout():
     for th, ky in enumerate((1, 3)):
         for slot, kx in enumerate((1, 0, 2)):
             assert np.array_equal(ph1[th, slot, 0, :, 5], hb[5, :, ky, kx])
+
+
+def _json_lines(text):
+    import json
+    out = []
+    for line in text.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            out.append(json.loads(line))
+    return out
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` started as ONE process starts its two ranks itself (torch.distributed.run as a
+    child), shards the global batch with shard_batch and rank 0 prints one line carrying ranks_seen and every
+    rank's time.  Host-side check (--plumbing-only: gloo, no GPU, no compute)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["OMP_NUM_THREADS"] = "2"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1, out.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
+    assert line["per_rank_batch"] == [64, 64] and len(line["per_rank_ms"]) == 2
+    # a fixed global batch (256 utterances over 3 ranks) is strong scaling, rows differ by at most one
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--plumbing-only",
+                          "--global-batch", "256"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = _json_lines(out.stdout)[0]
+    assert line["ranks_seen"] == 3 and line["scaling"] == "strong" and sum(line["per_rank_batch"]) == 256
+
+
+def test_bench_refuses_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr

@@ -10,11 +10,15 @@
   udss     UDSS(type_norm="BatchNorm2d") complex-valued network, sf [32,4,257,512,2], SV [32,4,514], theta [32,2]
 
 One JSON line per workload: audio-seconds/s (4.0 s per utterance), ms per step and the algorithmic
-GFLOP per utterance it implies.  Run it under ``rocprofv3 --kernel-trace --stats`` for the per-kernel
+GFLOP per utterance it implies.  ``--gpus N`` starts N ranks (one per GPU, RCCL) like bench.py does: every rank
+runs its unet_amd.sharding.shard_batch rows of ``--global-batch`` (default ``--batch`` per GPU; cfg 3 is
+``--only unet20 --gpus 8 --global-batch 256``), the step time is the maximum over ranks between barriers and the
+value is the whole job's.  Run it under ``rocprofv3 --kernel-trace --stats`` for the per-kernel
 times behind the bandwidth figures of the depthwise / mask kernels.
 """
 
 import argparse
+import importlib.util
 import json
 import math
 import os
@@ -29,15 +33,28 @@ sys.path.insert(0, ROOT)
 AUDIO_SECONDS = 4.0
 
 
+RANKS = None        # unet_amd.launch.Ranks of this process
+
+
+def load_by_path(name):
+    spec = importlib.util.spec_from_file_location("unetmi_" + name, os.path.join(ROOT, "unet_amd", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def timed(fn, steps, warmup):
+    """Seconds per step: barrier + synchronize either side of the timed steps, maximum over ranks."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    RANKS.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    RANKS.barrier()
+    return max(RANKS.gather_float((time.perf_counter() - t0) / steps))
 
 
 def main():
@@ -48,12 +65,23 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="activation storage of the resunet / dsunet workloads (arithmetic is fp32 either way)")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--global-batch", type=int, default=0, help="fixed global batch sharded over the ranks")
     args = ap.parse_args()
+    global RANKS
+    launcher = load_by_path("launch")
+    if launcher.needs_self_launch(args.gpus):
+        sys.exit(launcher.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    RANKS = launcher.init_ranks(args.gpus)
     import unet_amd
     from unet_amd.ops import crf_apply
-    dev = torch.device("cuda", 0)
-    B = args.batch
-    g = torch.Generator().manual_seed(4321)
+    from unet_amd.sharding import shard_batch
+    dev = RANKS.device
+    total = args.global_batch if args.global_batch else args.batch * RANKS.world
+    lo, hi = shard_batch(total, RANKS.rank, RANKS.world)
+    B = hi - lo
+    g = torch.Generator().manual_seed(4321 + lo)
+    seen = RANKS.ranks_seen()
 
     act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
@@ -61,7 +89,9 @@ def main():
         """One JSON line.  The roofline entry prices the WHOLE forward against the peak that bounds its dominant
         kernels: the fp32 or (bfloat16 operands) bf16 dense MFMA peak, or -- ResUNet -- HBM bandwidth over the
         algorithmic bytes of its residual-block layers (one read + one write of the activation per layer)."""
-        tflops = gflop * B / sec / 1e3
+        if RANKS.rank != 0:
+            return
+        tflops = gflop * B / sec / 1e3                     # per GPU (rank 0's share)
         if hbm_gb is not None:
             ach = hbm_gb * B / sec
             roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
@@ -69,8 +99,9 @@ def main():
         else:
             peak = 2500.0 if bf16_operands else 157.3
             roof = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak}
-        print(json.dumps({"workload": name, "value": B * AUDIO_SECONDS / sec, "unit": "audio-s/s",
-                          "ms_per_step": 1e3 * sec, "batch": B, "dtype": dtype,
+        print(json.dumps({"workload": name, "value": total * AUDIO_SECONDS / sec, "unit": "audio-s/s",
+                          "ms_per_step": 1e3 * sec, "batch": B, "global_batch": total, "n_gpus": RANKS.world,
+                          "ranks_seen": seen, "scaling": "strong" if args.global_batch else "weak", "dtype": dtype,
                           "gflop_per_utterance": gflop, "tflops": tflops, "roofline": roof,
                           "config": workload}), flush=True)
 
@@ -135,6 +166,7 @@ def main():
             report("udss", sec, round(udss_gflop(), 2), "UDSS(type_norm='BatchNorm2d') complex-valued forward, "
                                                         "sf [B,4,257,512,2], SV [B,4,514], theta [B,2]", args.dtype,
                    bf16_operands=args.dtype == "bf16")
+    RANKS.shutdown()
 
 
 def udss_gflop():

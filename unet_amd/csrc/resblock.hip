@@ -24,6 +24,7 @@
 
 #include "../../include/unetmi.h"
 #include "io_types.hpp"
+#include "resblock_common.hpp"
 
 namespace unetmi {
 
@@ -31,24 +32,6 @@ int api_fail(int code, const std::string& msg);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kRbC = 64;        // channels
-constexpr int kRbTR = 4;        // tile rows
-
-struct ResblockArgs {
-    const void* x;
-    const void* x2;         // optional addend of the input (x + x2)
-    const float* dw_w;      // [64][3][3]
-    const float* dw_b;      // [64] or null
-    const float* pw_w;      // [64 out][64 in]
-    const float* pw_b;      // [64] or null
-    const float* alpha;     // PReLU parameter [1]
-    const float* scale;     // folded BatchNorm [64]
-    const float* shift;
-    void* out;
-    int N, H, W, residual, act_first;
-    int tiles_h, tiles_w, ntiles;
-};
 
 // DWISE = false drops the depthwise stage: a plain 64 -> 64 pointwise convolution (D = 0, no halo),
 // whose input chunk is parked straight into the B-operand layout.
@@ -335,9 +318,16 @@ int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const 
     a.alpha = prelu_alpha; a.scale = bn_scale; a.shift = bn_shift; a.out = out;
     a.N = N; a.H = H; a.W = W; a.residual = residual ? 1 : 0; a.act_first = 1;
     const bool bf16 = dtype == UNETMI_DTYPE_BF16;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dilation_w != 1 && dilation_w != 2 && dilation_w != 4 && dilation_w != 8 && dilation_w != 16)
+        return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: time dilation must be 1, 2, 4, 8 or 16");
+    // fp32 tensors, one input: the LDS-DMA pipeline; bfloat16 storage or an input addend: the register-staged kernel
+    if (!bf16 && !x2 && (long long)C * H * W * 4 < 0x20000000ll && H < 30000) {
+        const hipError_t e = launch_resblock_dma(dilation_w, s, a);
+        return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("resblock_layer launch: ") + hipGetErrorString(e));
+    }
     const int grid = fill_tiles(a, bf16);
     if (grid < 0) return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: too many tiles");
-    hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e;
     switch (dilation_w) {
         case 1: e = launch_resblock<1, true>(grid, s, a, bf16); break;

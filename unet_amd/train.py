@@ -18,6 +18,7 @@ optimizer is one kernel.
 """
 
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -333,7 +334,7 @@ class FlatBucket:
         size, by which the caller divides (FlatAdam.step folds the division into the update)."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            if dist.get_backend(group) == "gloo" and self.grad.is_cuda:
+            if dist.get_backend(group) == "gloo" and self.grad.is_cuda and os.environ.get("UNETMI_GLOO_DEVICE_TENSORS") != "1":
                 # gloo stages device tensors through the host on its own streams; do the staging here,
                 # synchronously, so the exchange cannot interleave with this process's queued kernels
                 host = self.grad.cpu()
