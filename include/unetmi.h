@@ -189,6 +189,18 @@ int unetmi_pwconv64_fwd(int N, int H, int W, const void* x, const void* x2, cons
 int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, void* sync_ws,
                            void* stream);
 
+/* The same recurrence with the batch split over the chip's 8 XCDs (4 batch columns each, BP <= 32): every XCD runs
+ * an independent recurrence for its columns, the state exchange stays inside that XCD's L2 and there is no
+ * device-wide barrier (about 2 us per step instead of 6-7).  Arguments and results as unetmi_lstm_recurrence.
+ * ws: unetmi_lstm_recurrence_xcd_workspace_bytes() bytes of device scratch (cleared by the call).  Needs a
+ * device of 8 XCDs x 32 compute units with one workgroup resident per compute unit (UNETMI_E_UNSUPPORTED
+ * otherwise: use unetmi_lstm_recurrence).  A workgroup finds its XCD from the hardware, not from its index.
+ * Status: ((uint32_t*)ws)[8] is non-zero after an aborted run (a workgroup was not resident, e.g. the GPU is
+ * shared); every slot of hfull from the aborted step on is then NaN. */
+size_t unetmi_lstm_recurrence_xcd_workspace_bytes(void);
+int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, void* ws,
+                               size_t ws_bytes, void* stream);
+
 /* LayerNorm over the FREQUENCY axis of x[N,C,F,T] (biased variance, affine gamma/beta[F]),
  * written into channels [c_off, c_off+C) of out[N,C_out,F,T].  Replaces
  *   permute -> nn.LayerNorm(257) on [B,C,T,F] -> permute -> torch.cat       ResUNet.py:165-175, :49, :53

@@ -127,13 +127,16 @@ def test_dsunet_full_length(device):
     print("DSUNet T=512: worst layer sample error {:.2e}, output rel-err vs oracle {:.2e}".format(worst, e))
 
 
-def test_projected_lstm_full_length(device):
-    """lstm_forward at the benchmark's shape (batch 32, 501 steps, three layers) against torch's CPU LSTM; the
+@pytest.mark.parametrize("kernel", ["xcd", "grid"])
+def test_projected_lstm_full_length(device, kernel, monkeypatch):
+    """lstm_forward (both recurrence kernels) at the benchmark's shape (batch 32, 501 steps, three layers) against torch's CPU LSTM; the
     error is reported for the whole sequence and for the last step, where 501 steps of rounding have accumulated."""
     import copy
     import unet_amd
+    import unet_amd.lstm
     from unet_amd.lstm import lstm_forward
     from unet_amd.seeding import normal
+    monkeypatch.setattr(unet_amd.lstm, "KERNEL", kernel)
     ref = torch.nn.LSTM(384, 640, 3, batch_first=True, proj_size=384)
     holder = torch.nn.Module()
     holder.lstm = ref
@@ -146,7 +149,7 @@ def test_projected_lstm_full_length(device):
     assert not torch.isnan(got).any(), "the recurrence kernel aborted"
     e_all = rel_err(got, want)
     e_last = rel_err(got[:, -1], want[:, -1])
-    print("projected LSTM B=32 T=501: rel-err {:.2e} over the sequence, {:.2e} at step 501".format(e_all, e_last))
+    print("projected LSTM ({}) B=32 T=501: rel-err {:.2e} over the sequence, {:.2e} at step 501".format(kernel, e_all, e_last))
     assert e_all <= 1e-4 and e_last <= 1e-4
     # a second run gives the same bits: no read of a state row that is still in flight
     again = lstm_forward(dev, x.to(device), {}).cpu()

@@ -37,6 +37,8 @@ EXPORTED_SYMBOLS = (
     "unetmi_resblock_layer_fwd",
     "unetmi_pwconv64_fwd",
     "unetmi_lstm_recurrence",
+    "unetmi_lstm_recurrence_xcd_workspace_bytes",
+    "unetmi_lstm_recurrence_xcd",
     "unetmi_glu_fwd",
     "unetmi_conv2d_b16_packed_weight_bytes",
     "unetmi_conv2d_b16_pack_weights",
@@ -104,6 +106,10 @@ def _load():
     lib.unetmi_pwconv64_fwd.restype = ctypes.c_int
     lib.unetmi_lstm_recurrence.argtypes = [ci] * 3 + [fp] * 3 + [vp, vp]
     lib.unetmi_lstm_recurrence.restype = ctypes.c_int
+    lib.unetmi_lstm_recurrence_xcd_workspace_bytes.argtypes = []
+    lib.unetmi_lstm_recurrence_xcd_workspace_bytes.restype = ctypes.c_size_t
+    lib.unetmi_lstm_recurrence_xcd.argtypes = [ci] * 3 + [fp] * 3 + [vp, ctypes.c_size_t, vp]
+    lib.unetmi_lstm_recurrence_xcd.restype = ctypes.c_int
     lib.unetmi_glu_fwd.argtypes = [ci] * 3 + [fp] * 3 + [ci] + [fp] * 3 + [ci, vp]
     lib.unetmi_glu_fwd.restype = ctypes.c_int
     lib.unetmi_adam_step.argtypes = [sz] + [fp] * 4 + [cf] * 6 + [ci, vp]

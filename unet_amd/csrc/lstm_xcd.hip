@@ -1,0 +1,229 @@
+// Recurrent part of the projected LSTM bottleneck (nn.LSTM(384, 640, 3, proj_size=384), ResUNet.py:139) with the
+// state exchange kept INSIDE each XCD.
+//
+// lstm.hip gives every workgroup four hidden units for all batch columns, so each step every workgroup reads the
+// whole state (80 KB) with device-coherent loads: 13 MB per step cross the fabric and a step takes 6-7 us.  Here
+// the BATCH is split over the chip's 8 XCDs instead: XCD x owns batch columns [4x, 4x+4) and runs a complete,
+// independent recurrence for them -- no XCD ever reads another's state, so the exchange is served by the XCD's
+// own L2 (device-scope loads, which skip the per-CU cache) and there is no device-wide barrier at all.
+//
+// Inside an XCD the 32 workgroups (one per compute unit) split the hidden units, 20 each = 80 rows of the folded
+// recurrent matrix Wrec = W_hh W_hr [4H x H].  A workgroup keeps its 80 x 640 slice in REGISTERS for all T steps:
+// wave w holds columns [160w, 160w+160) as 200 A operands of v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4x1
+// blocks per instruction: 4 hidden units x 4 values of k; a block's 4 rows are the 4 gates of one unit, its 4
+// columns the XCD's 4 batch columns).  Per step a wave
+//   * reads its quarter of the state h_t (640 values) as 8-byte {value, step} granules, written by one store
+//     and read by one load each, so a granule is either old or new, never torn, and carries its own readiness:
+//     no flag, no wait for store completion on the producer side; the wave retries until all its tags read t;
+//   * issues 200 MFMAs, sums the 4 k-blocks of a unit with two DPP adds and leaves its partial sums in LDS;
+// then (one workgroup barrier) 80 threads add the four waves' partials and the input contribution, apply the
+// gate nonlinearities, keep the cell state in a register, and publish the new state granules (double-buffered
+// by step parity) and the state row of the caller's output.
+//
+// Placement: a workgroup reads the XCD it actually runs on from the hardware (XCC_ID) and takes a ticket for a
+// slot of that XCD, so correctness never depends on the dispatcher's round-robin; if an XCD ends up short of
+// workgroups (the GPU is shared), the bounded spin raises the abort word, everything from that step on is NaN
+// and the status word stays non-zero for the caller.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <string>
+
+#include "../../include/unetmi.h"
+
+namespace unetmi {
+
+int api_fail(int code, const std::string& msg);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kXH = 640;                 // hidden size
+constexpr int kXcds = 8, kXWg = 32;      // XCDs, workgroups (compute units) per XCD
+constexpr int kXU = kXH / kXWg;          // hidden units per workgroup (20)
+constexpr int kXSets = kXU / 4;          // MFMA accumulator sets: 4 units each (5)
+constexpr int kXKg = kXH / 4 / 4;        // k-groups per wave: 160 columns / 4 per instruction (40)
+constexpr int kXCols = 4;                // batch columns per XCD
+constexpr unsigned kXSpinLimit = 1u << 20;
+
+struct LstmXcdArgs {
+    const float* wrec;          // [4H][H]
+    const float* gx;            // [T][4H][BP]
+    float* hfull;               // [T+1][H][BP]
+    unsigned* ctl;              // [8] tickets, [8] abort word (+ padding to 64 words)
+    unsigned long long* hx;     // [8 XCDs][2 parities][H][4] granules {float value, unsigned step}
+    int T, BP;
+};
+
+__device__ __forceinline__ float sigmoid_x(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {     // v + (v moved by the DPP control), within rows of 16 lanes
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, moved);
+}
+
+__global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
+    __shared__ float s_h[4][kXH];                          // per wave: its quarter of the state, [k][col]
+    __shared__ float s_part[2][4][kXSets][4][16];          // [parity][wave][set][gate][unit-in-set * 4 + col]
+    __shared__ int s_slot;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- where am I: XCD from the hardware, slot from a per-XCD ticket ----
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int xcd = (int)(xcc & 7u);
+    if (tid == 0) s_slot = (int)__hip_atomic_fetch_add(&a.ctl[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int slot = s_slot;
+    const int col0 = xcd * kXCols;
+    if (slot >= kXWg || col0 >= a.BP) return;              // surplus workgroup, or an XCD without batch columns
+
+    // ---- lane roles.  lane = 16*ui + 4*ki + r: A operand row r = gate r of unit ui of the set, B/D column r ----
+    const int ui = lane >> 4, ki = (lane >> 2) & 3, r = lane & 3;
+    const int u_base = slot * kXU;
+    float A[kXSets][kXKg];
+#pragma unroll
+    for (int s = 0; s < kXSets; ++s) {
+        const float* row = a.wrec + (size_t)(r * kXH + u_base + 4 * s + ui) * kXH + 160 * wave + ki;
+#pragma unroll
+        for (int kg = 0; kg < kXKg; ++kg) A[s][kg] = row[4 * kg];
+    }
+    // gate thread: cell (unit ul, column cj) of this workgroup
+    const bool gate_thread = tid < kXU * kXCols;
+    const int ul = tid >> 2, cj = tid & 3;
+    const bool col_live = col0 + cj < a.BP;
+    float c = 0.f;
+
+    unsigned long long* hx = a.hx + (size_t)xcd * 2 * kXH * kXCols;
+    float* sh = s_h[wave];
+    bool alive = true;
+    int t = 0;
+    for (; t < a.T; ++t) {
+        // this step's input contribution, fetched while the state is awaited
+        float gxv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gate_thread && col_live) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                gxv[g] = a.gx[((size_t)t * 4 * kXH + g * kXH + u_base + ul) * a.BP + col0 + cj];
+        }
+        // ---- this wave's quarter of h_t: granules (160*wave + e/4, e%4), e = lane + 64*i, until all read step t ----
+        const unsigned long long* src = hx + (size_t)(t & 1) * kXH * kXCols + (size_t)wave * 160 * kXCols;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+            float v[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                // device-scope loads: they never hit this compute unit's vector cache (a line cached before the
+                // producers' stores would otherwise be hit again and again) and are served by the XCD's L2, where
+                // those stores land.  Measured alternatives: invalidating the vector cache before plain loads is 3x
+                // slower per step, non-temporal loads the same speed.
+                const unsigned long long g =
+                    __hip_atomic_load(&src[lane + 64 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[i] = __builtin_bit_cast(float, (unsigned)(g & 0xffffffffull));
+                ok = ok && (unsigned)(g >> 32) == (unsigned)t;
+            }
+            if (__all(ok)) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) sh[lane + 64 * i] = v[i];
+                break;
+            }
+            if ((++spins & 63u) == 0u) {
+                const unsigned stop = __hip_atomic_load(&a.ctl[kXcds], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (stop != 0u || spins > kXSpinLimit) {
+                    if (lane == 0) __hip_atomic_store(&a.ctl[kXcds], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    alive = false;
+                    break;
+                }
+            }
+        }
+        // ---- 200 MFMAs: acc[s] block (ui, ki) += A rows (4 gates of unit 4s+ui) x B (h[k][0..3]), k = 160w + 4kg + ki ----
+        f32x4 acc[kXSets];
+#pragma unroll
+        for (int s = 0; s < kXSets; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kg = 0; kg < kXKg; ++kg) {
+            const float bv = sh[(4 * kg + ki) * kXCols + r];
+#pragma unroll
+            for (int s = 0; s < kXSets; ++s) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[s][kg], bv, acc[s], 0, 0, 0);
+        }
+        // sum the 4 k-blocks of a unit (lanes 4*ki apart inside a row of 16), leave the partials in LDS
+        float* part = &s_part[t & 1][wave][0][0][0];
+#pragma unroll
+        for (int s = 0; s < kXSets; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float x = acc[s][g];
+                x = dpp_add<0x128>(x);          // row_ror:8
+                x = dpp_add<0x124>(x);          // row_ror:4
+                if (ki == 0) part[(s * 4 + g) * 16 + ui * 4 + r] = x;
+            }
+        if (!__syncthreads_and(alive ? 1 : 0)) break;       // partials visible; if some wave gave up, leave together
+        // ---- gates, cell, new state ----
+        if (gate_thread) {
+            const int s = ul >> 2, uu = ul & 3;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int idx = (s * 4 + g) * 16 + uu * 4 + cj;
+                pre[g] = gxv[g] + ((s_part[t & 1][0][0][0][idx] + s_part[t & 1][1][0][0][idx]) +
+                                   (s_part[t & 1][2][0][0][idx] + s_part[t & 1][3][0][0][idx]));
+            }
+            const float ig = sigmoid_x(pre[0]), fg = sigmoid_x(pre[1]), gg = tanhf(pre[2]), og = sigmoid_x(pre[3]);
+            c = fg * c + ig * gg;
+            const float hn = col_live ? og * tanhf(c) : 0.f;
+            const unsigned long long granule =
+                (unsigned long long)__builtin_bit_cast(unsigned, hn) | ((unsigned long long)(unsigned)(t + 1) << 32);
+            // written through the vector cache into the XCD's L2, which is where this XCD's readers look; the
+            // device-scope (memory-side) form of the store costs 0.6 us more per step and is not needed: no other
+            // XCD ever reads these granules
+            __hip_atomic_store(&hx[(size_t)((t + 1) & 1) * kXH * kXCols + (size_t)(u_base + ul) * kXCols + cj], granule,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (col_live) a.hfull[((size_t)(t + 1) * kXH + u_base + ul) * a.BP + col0 + cj] = hn;
+        }
+    }
+    // Aborted at step t: every state row from that step on is NaN so that nothing computed from a state that was
+    // never exchanged can pass for a result (the abort word stays raised for the caller as well).
+    if (t < a.T && gate_thread && col_live)
+        for (int tt = t + 1; tt <= a.T; ++tt) a.hfull[((size_t)tt * kXH + u_base + ul) * a.BP + col0 + cj] = __builtin_nanf("");
+}
+
+}  // namespace unetmi
+
+using namespace unetmi;
+
+extern "C" size_t unetmi_lstm_recurrence_xcd_workspace_bytes(void) {
+    return 64 * sizeof(unsigned) + (size_t)kXcds * 2 * kXH * kXCols * sizeof(unsigned long long);
+}
+
+extern "C" int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wrec, const float* gx, float* hfull,
+                                          void* ws, size_t ws_bytes, void* stream) {
+    if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence_xcd: bad sizes");
+    if (H != kXH) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: built for hidden size 640");
+    if (BP > kXcds * kXCols) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: at most 32 batch columns per launch");
+    if (T == 0) return UNETMI_OK;
+    if (!wrec || !gx || !hfull || !ws) return api_fail(UNETMI_E_BAD_ARG, "lstm_recurrence_xcd: null pointer");
+    if (ws_bytes < unetmi_lstm_recurrence_xcd_workspace_bytes())
+        return api_fail(UNETMI_E_BAD_ARG, "lstm_recurrence_xcd: workspace too small");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return api_fail(UNETMI_E_HIP, "lstm_recurrence_xcd: cannot query the device");
+    // one workgroup per compute unit, 32 compute units on each of 8 XCDs
+    if (cus != kXcds * kXWg) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: needs 8 XCDs of 32 compute units");
+    int per_cu = 0;
+    const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_kernel, 256, 0);
+    if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd occupancy query: ") + hipGetErrorString(oe));
+    if (per_cu < 1) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: the kernel does not fit a compute unit");
+    LstmXcdArgs a{};
+    a.wrec = wrec; a.gx = gx; a.hfull = hfull; a.T = T; a.BP = BP;
+    a.ctl = static_cast<unsigned*>(ws);
+    a.hx = reinterpret_cast<unsigned long long*>(static_cast<unsigned*>(ws) + 64);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // tickets, abort word and the state granules start from zero: h_0 = 0 carrying step tag 0
+    hipError_t e = hipMemsetAsync(ws, 0, unetmi_lstm_recurrence_xcd_workspace_bytes(), s);
+    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd memset: ") + hipGetErrorString(e));
+    hipLaunchKernelGGL(lstm_xcd_kernel, dim3(kXcds * kXWg), dim3(256), 0, s, a);
+    e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd launch: ") + hipGetErrorString(e));
+}

@@ -12,7 +12,13 @@ import torch.nn as nn
 from . import _lib
 from ._lib import check
 
-MAX_BATCH_PER_LAUNCH = 64
+MAX_BATCH_PER_LAUNCH = 64          # device-wide-barrier kernel (unetmi_lstm_recurrence)
+XCD_BATCH_PER_LAUNCH = 32          # XCD-local kernel (unetmi_lstm_recurrence_xcd): 8 XCDs x 4 batch columns
+
+# Which recurrence kernel lstm_forward uses: "xcd" (batch split over the XCDs, state exchange inside each XCD's
+# L2; falls back to "grid" on a device it does not fit) or "grid" (every workgroup reads the whole state, one
+# device-wide barrier per step).
+KERNEL = "xcd"
 
 
 def supported(lstm):
@@ -33,6 +39,29 @@ def _folded_recurrent_matrix(lstm, layer, cache):
     return hit[1]
 
 
+def _xcd_kernel_fits(dev):
+    return KERNEL == "xcd" and torch.cuda.get_device_properties(dev).multi_processor_count == 256
+
+
+def _recurrence(T, BP, H, wrec, gx, hfull, scratch, use_xcd):
+    """One layer's T dependent steps; returns the kernel's status word (a device scalar, non-zero = aborted)."""
+    stream = torch.cuda.current_stream().cuda_stream
+    if use_xcd:
+        nbytes = _lib.lib.unetmi_lstm_recurrence_xcd_workspace_bytes()
+        ws = scratch.get("xcd")
+        if ws is None or ws.device != gx.device:
+            ws = scratch["xcd"] = torch.empty(nbytes // 4, dtype=torch.int32, device=gx.device)
+        check(_lib.lib.unetmi_lstm_recurrence_xcd(T, BP, H, wrec.data_ptr(), gx.data_ptr(), hfull.data_ptr(),
+                                                  ws.data_ptr(), nbytes, stream), "unetmi_lstm_recurrence_xcd")
+        return ws[8]
+    sync = scratch.get("grid")
+    if sync is None or sync.device != gx.device:
+        sync = scratch["grid"] = torch.empty(H // 4 + 1, dtype=torch.int32, device=gx.device)
+    check(_lib.lib.unetmi_lstm_recurrence(T, BP, H, wrec.data_ptr(), gx.data_ptr(), hfull.data_ptr(),
+                                          sync.data_ptr(), stream), "unetmi_lstm_recurrence")
+    return sync[-1]
+
+
 def lstm_forward(lstm, x, cache):
     """x [B, T, input] -> [B, T, proj]; zero initial state, inference only."""
     if not supported(lstm):
@@ -40,17 +69,18 @@ def lstm_forward(lstm, x, cache):
     if not x.is_cuda or x.dtype != torch.float32:
         raise ValueError("lstm_forward: x must be an fp32 device tensor")
     B, T, _ = x.shape
-    if B > MAX_BATCH_PER_LAUNCH:                    # sequences are independent: run them in groups
-        return torch.cat([lstm_forward(lstm, x[i:i + MAX_BATCH_PER_LAUNCH], cache)
-                          for i in range(0, B, MAX_BATCH_PER_LAUNCH)], dim=0)
+    use_xcd = _xcd_kernel_fits(x.device)
+    group = XCD_BATCH_PER_LAUNCH if use_xcd else MAX_BATCH_PER_LAUNCH
+    if B > group:                                   # sequences are independent: run them in groups
+        return torch.cat([lstm_forward(lstm, x[i:i + group], cache) for i in range(0, B, group)], dim=0)
     H = lstm.hidden_size
     BP = (B + 15) // 16 * 16
     dev = x.device
-    with torch.no_grad():
+    with torch.no_grad(), torch.cuda.device(dev):
         seq = torch.zeros((T, x.shape[2], BP), dtype=torch.float32, device=dev)      # [T, in, BP]
         seq[:, :, :B] = x.permute(1, 2, 0)
-        sync = torch.empty(lstm.hidden_size // 4 + 1, dtype=torch.int32, device=dev)
         aborted = torch.zeros((), dtype=torch.int32, device=dev)
+        scratch = {}
         for layer in range(lstm.num_layers):
             w_ih = getattr(lstm, "weight_ih_l{}".format(layer)).detach().float()
             w_hr = getattr(lstm, "weight_hr_l{}".format(layer)).detach().float()
@@ -59,13 +89,10 @@ def lstm_forward(lstm, x, cache):
             wrec = _folded_recurrent_matrix(lstm, layer, cache)
             hfull = torch.empty((T + 1, H, BP), dtype=torch.float32, device=dev)
             hfull[0].zero_()
-            with torch.cuda.device(dev):
-                check(_lib.lib.unetmi_lstm_recurrence(T, BP, H, wrec.data_ptr(), gx.data_ptr(), hfull.data_ptr(),
-                                                      sync.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                      "unetmi_lstm_recurrence")
-            aborted = aborted | sync[-1]                                              # the kernel's status word, kept on the device
+            status = _recurrence(T, BP, H, wrec, gx, hfull, scratch, use_xcd)
+            aborted = aborted | status                                                # the kernel's status word, kept on the device
             seq = torch.matmul(w_hr, hfull[1:])                                       # [T, proj, BP] = next layer's input
         out = seq[:, :, :B].permute(2, 0, 1).contiguous()
-        # a recurrence whose device-wide barrier timed out (GPU shared with other work) must not pass for a
-        # result: the whole output becomes NaN, without a host round trip
+        # a recurrence that gave up waiting (GPU shared with other work) must not pass for a result: the whole
+        # output becomes NaN, without a host round trip
         return torch.where(aborted != 0, torch.full_like(out, float("nan")), out)
