@@ -458,6 +458,31 @@ def test_dsunet_bf16(device):
     assert dev._blocked, "the blocked bf16 path was not taken"
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 9, 70), (1, 64, 257, 29), (3, 64, 3, 200), (8, 64, 6, 501), (8, 64, 13, 500)])
+def test_resblock_64_bf16_storage(device, shape):
+    """The 64-channel block on bfloat16 tensors: five layers, each rounding its output once; against the fp32 oracle
+    on the same (bf16-representable) input.  Even widths take the LDS-DMA layer kernel (8 activations per 16-byte
+    group), odd widths (rows not 4-byte aligned) the register-staged one."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    ref = oracle.ResBlock(64).eval()
+    unet_amd.seeded_fill_(ref, seed=33)
+    dev = unet_amd.ResBlock(64)
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    x = normal("rb64/xbf", shape, seed=35).to(torch.bfloat16)
+    with torch.no_grad():
+        want = ref(x.float())
+        got = dev(x.to(device))
+    assert got.dtype == torch.bfloat16
+    g, w = got.float().cpu(), want
+    l2 = ((g - w).norm() / w.norm()).item()
+    mx = ((g - w).abs().max() / w.abs().max()).item()
+    print("ResBlock(64) bf16 {}: relative L2 {:.2e}, max-norm {:.2e}".format(shape, l2, mx))
+    assert l2 <= 5e-3 and mx <= 1e-2
+
+
 @pytest.mark.parametrize("geom", [(64, 64, (3, 3), (2, 1), (0, 1), False), (64, 64, (4, 1), (2, 1), (1, 0), True),
                                   (20, 7, (5, 3), (2, 1), (2, 1), False), (2, 32, (7, 1), (1, 1), (3, 0), False)])
 def test_conv_bf16_storage(device, geom):

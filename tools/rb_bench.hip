@@ -13,6 +13,7 @@
 
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 32, H = argc > 2 ? atoi(argv[2]) : 257, W = argc > 3 ? atoi(argv[3]) : 501;
+    const bool bf16 = argc > 4 && atoi(argv[4]) != 0;      // the buffers are oversized for bf16; values are arbitrary bits
     const size_t n = (size_t)N * 64 * H * W;
     std::vector<float> hx(n);
     unsigned s = 12345u;
@@ -30,17 +31,17 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int ds[6] = {16, 1, 2, 4, 8, 16};
     for (int di = 0; di < 6; ++di) {
-        for (int i = 0; i < 2; ++i) CK(unetmi::launch_resblock_dma(ds[di], nullptr, a));
+        for (int i = 0; i < 2; ++i) CK(unetmi::launch_resblock_dma(ds[di], nullptr, a, bf16));
         CK(hipEventRecord(e0, nullptr));
         const int reps = 10;
-        for (int i = 0; i < reps; ++i) CK(unetmi::launch_resblock_dma(ds[di], nullptr, a));
+        for (int i = 0; i < reps; ++i) CK(unetmi::launch_resblock_dma(ds[di], nullptr, a, bf16));
         CK(hipEventRecord(e1, nullptr));
         CK(hipEventSynchronize(e1));
         float ms = 0.f;
         CK(hipEventElapsedTime(&ms, e0, e1));
         ms /= reps;
         const double pix = (double)N * H * W;
-        printf("d=%-2d %.3f ms  %.2f TB/s algorithmic  %.1f ps/pixel\n", ds[di], ms, 2.0 * n * 4 / ms / 1e9, ms * 1e9 / pix);
+        printf("d=%-2d %.3f ms  %.2f TB/s algorithmic  %.1f ps/pixel\n", ds[di], ms, 2.0 * n * (bf16 ? 2 : 4) / ms / 1e9, ms * 1e9 / pix);
     }
     return 0;
 }

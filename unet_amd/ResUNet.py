@@ -7,8 +7,8 @@ What runs where:
     straight into its channel range of the 64-channel tensor (no permute, no cat);
   * encoders / decoders / res-paths: fused conv launches (PReLU + BatchNorm in the
     epilogue, ``y + res`` read as two inputs), ResBlocks as in ``UNet_m.ResBlock``;
-  * bottleneck: ``nn.LSTM(384, 640, 3, proj_size=384)`` runs as torch's own device
-    LSTM -- the one part of this model that is not a kernel of this library;
+  * bottleneck: ``nn.LSTM(384, 640, 3, proj_size=384)``: the 501-step recurrence of each layer is one
+    persistent launch (unet_amd/lstm.py), its time-parallel products are GEMMs;
   * output: transposed (3,1) conv to 2 channels, then (tanh(y) + 1e-13) * input[:, :2]
     as one launch.
 """
@@ -47,16 +47,25 @@ def _trunk(net, x, bottleneck=None):
     for i, rp in enumerate(net.res_paths):
         res[i] = rp(res[i])
 
+    # ``y = y + res[-1-i]; y = dec(y)`` (ResUNet.py:206-210).  Where decoder i ends in a transposed conv and decoder
+    # i+1 starts with a ResBlock, the NEXT add is done in that conv's epilogue (same two fp32 operands, same
+    # sum), so every ResBlock layer reads a single tensor; a Decoder-first block reads y and res as two inputs.
+    n_dec = len(net.decoders)
+    added = False                                      # res[-1-i] is already inside y
     for i, dec in enumerate(net.decoders):
         skip = res[-1 - i]
         if net.print_shape:
             print("y {} += r_{} : {}".format(y.shape, i, skip.shape))
+        nxt = net.decoders[i + 1] if i + 1 < n_dec else None
+        ends_in_conv = isinstance(dec, Decoder) or not isinstance(dec, ResBlock)
+        next_skip = res[-2 - i] if (ends_in_conv and nxt is not None and not isinstance(nxt, Decoder)) else None
         if isinstance(dec, Decoder):
-            y = dec(y, skip, add=True)                 # y + res read as two kernel inputs
+            y = dec(y, skip, add=True, residual=next_skip)       # y + res read as two kernel inputs
         elif isinstance(dec, ResBlock):
-            y = dec(y, add=skip)
+            y = dec(y) if added else dec(y, add=skip)
         else:                                          # Sequential(ResBlock, Decoder)
-            y = dec[1](dec[0](y, add=skip))
+            y = dec[1](dec[0](y) if added else dec[0](y, add=skip), residual=next_skip)
+        added = next_skip is not None
         if net.print_shape:
             print("y_{} : {}".format(i, y.shape))
     return y

@@ -59,17 +59,22 @@ class _FusedBlock(nn.Module):
                                FusedConv(getattr(self, self._conv_attr), self.bn, self.acti))
         return self._fused
 
-    def _run(self, x, skip=None, in_mode=None, gate=None):
+    def _run(self, x, skip=None, in_mode=None, gate=None, residual=None):
         require_device_tensor(x, type(self).__name__)
         if self.training:
+            if residual is not None:
+                raise NotImplementedError("{}: differentiable forward with an added tensor is not built".format(
+                    type(self).__name__))
             return self._run_differentiable(x, skip, in_mode, gate)
         layer = self._layer()
         if layer.fusable():
-            return layer(x, skip, in_mode=in_mode, gate=gate)
+            return layer(x, skip, in_mode=in_mode, gate=gate, residual=residual)
         y = layer(x, skip, in_mode=in_mode, epilogue=False)
         y = self.acti(self.bn(y))
         if gate is not None:
             y = y * gate[:, :, None, None]
+        if residual is not None:
+            y = y + residual
         return y
 
     def _run_differentiable(self, x, skip, in_mode, gate):
@@ -118,7 +123,7 @@ class Decoder(_FusedBlock):
 
     ``forward(x, skip)`` computes ``decoder(torch.cat([x, skip], 1))`` without
     forming the concatenation; ``forward(x, skip, add=True)`` computes
-    ``decoder(x + skip)``."""
+    ``decoder(x + skip)``; ``residual=`` adds a tensor to the output."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding=(0, 0), dilation=1,
                  output_padding=(0, 0), activation="LeakyReLU", norm="BatchNorm2d"):
@@ -131,8 +136,12 @@ class Decoder(_FusedBlock):
         self.acti = _activation(activation, "Encoder")
         self._setup("transconv")
 
-    def forward(self, x, skip=None, add=False):
-        return self._run(x, skip, in_mode=(_lib.IN_ADD if add else None) if skip is not None else None)
+    def forward(self, x, skip=None, add=False, residual=None):
+        """``residual`` (shaped like the output) is added to the block's output in the kernel's epilogue: the
+        ``y + res`` in front of the NEXT block of an additive-skip decoder (ResUNet.py:209), taken here so that
+        block reads one tensor."""
+        return self._run(x, skip, in_mode=(_lib.IN_ADD if add else None) if skip is not None else None,
+                         residual=residual)
 
 
 class ResBlock(nn.Module):

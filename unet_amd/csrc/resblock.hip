@@ -321,9 +321,10 @@ int unetmi_resblock_layer_fwd(int N, int C, int H, int W, int dilation_w, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dilation_w != 1 && dilation_w != 2 && dilation_w != 4 && dilation_w != 8 && dilation_w != 16)
         return api_fail(UNETMI_E_UNSUPPORTED, "resblock_layer: time dilation must be 1, 2, 4, 8 or 16");
-    // fp32 tensors, one input: the LDS-DMA pipeline; bfloat16 storage or an input addend: the register-staged kernel
-    if (!bf16 && !x2 && (long long)C * H * W * 4 < 0x20000000ll && H < 30000) {
-        const hipError_t e = launch_resblock_dma(dilation_w, s, a);
+    // one input: the LDS-DMA pipeline; with an input addend: the register-staged kernel.  The 16-byte DMA groups need
+    // 4-byte-aligned addresses: always true for fp32, for bfloat16 only when every row starts on an even element.
+    if (!x2 && (long long)C * H * W * 4 < 0x20000000ll && H < 30000 && (!bf16 || (W & 1) == 0)) {
+        const hipError_t e = launch_resblock_dma(dilation_w, s, a, bf16);
         return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("resblock_layer launch: ") + hipGetErrorString(e));
     }
     const int grid = fill_tiles(a, bf16);

@@ -1,5 +1,5 @@
 // Shared by the residual-block layer kernels (resblock.hip: register-staged, any storage type, optional input
-// addend; resblock_dma.hip: the fp32 LDS-DMA pipeline).
+// addend; resblock_dma.hip: the LDS-DMA pipeline for a single input).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,7 +23,8 @@ struct ResblockArgs {
     int tiles_h, tiles_w, ntiles;
 };
 
-// The fp32, single-input layer on the LDS-DMA pipeline (resblock_dma.hip).  Fills tiles_* / ntiles itself.
-hipError_t launch_resblock_dma(int dilation_w, hipStream_t s, ResblockArgs a);
+// The single-input layer on the LDS-DMA pipeline (resblock_dma.hip), fp32 or bfloat16 storage.  Fills tiles_* /
+// ntiles itself.
+hipError_t launch_resblock_dma(int dilation_w, hipStream_t s, ResblockArgs a, bool bf16);
 
 }  // namespace unetmi

@@ -1,4 +1,4 @@
-// One layer of the residual block (UNet_m.py:545-561) for fp32 tensors and a single input, as a software
+// One layer of the residual block (UNet_m.py:545-561) for a single input, as a software
 // pipeline in which every wave carries its share of ALL stages inside its own matrix-instruction stream:
 //
 //     out = [x +] BN(PReLU(pointwise_1x1(depthwise_3x3_dilated(x))))          64 channels
@@ -37,12 +37,15 @@
 // Workgroup -> tile order: when the batch is a multiple of 8, the workgroups of one XCD (blockIdx.x mod 8)
 // work through whole samples together, so neighbouring tiles' shared halo meets in that XCD's L2.
 //
-// The register-staged kernel in resblock.hip serves what this one does not: bfloat16 storage and the input
-// addend of a decoder block's first layer.
+// Storage: fp32, or bfloat16 (a 16-byte DMA group then holds 8 activations; they are widened when the depthwise
+// and the running-add copy read them out of LDS, and the result is rounded once on store); arithmetic is fp32
+// either way.  The register-staged kernel in resblock.hip serves what this one does not: the input addend of a
+// decoder block's first layer.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
 
+#include "io_types.hpp"
 #include "resblock_common.hpp"
 
 // Timing-only builds (tools/rb_bench.hip) switch stages off with -DRB_ABLATE=<bits> to price them; the library is
@@ -59,18 +62,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_void_ptr_rb;
 
-template <int D>
+template <int D, bool BF16>
 struct RbGeom {
+    static constexpr int EB = BF16 ? 2 : 4;                 // bytes of a stored activation
+    static constexpr int GE = 16 / EB;                      // activations of one 16-byte DMA group
     static constexpr int TC = 64, TR = kRbTR, CK = 4, NCH = kRbC / CK;
     static constexpr int PROWS = TR + 2;
-    static constexpr int DL = (D + 3) / 4 * 4;              // left halo rounded up to whole 4-column groups, so that no
-                                                            // group straddles the left border (tiles start at multiples of 64)
-    static constexpr int TCP = (DL + TC + D + 3) / 4 * 4;   // patch columns; column c = image column col0 - DL + c
-    static constexpr int QPR = TCP / 4;                     // 16-byte groups per patch row
+    static constexpr int DL = (D + GE - 1) / GE * GE;       // left halo rounded up to whole groups, so that no group
+                                                            // straddles the left border (tiles start at multiples of 64)
+    static constexpr int TCP = (DL + TC + D + GE - 1) / GE * GE;   // patch columns; column c = image column col0 - DL + c
+    static constexpr int QPR = TCP / GE;                    // 16-byte groups per patch row
     static constexpr int NQ = PROWS * QPR;                  // groups (= DMA lanes) of one channel's patch
     static constexpr int NDI = (NQ + 63) / 64;              // DMA instructions per wave and step
-    static constexpr int CHF = PROWS * TCP;                 // floats of one channel's patch
-    static constexpr int IN_FLOATS = CK * CHF;
+    static constexpr int CHB = PROWS * TCP * EB;            // bytes of one channel's patch
+    static constexpr int IN_BYTES = CK * CHB;
 #ifdef RB_RING
     static constexpr int RING = RB_RING;
 #else
@@ -84,8 +89,19 @@ struct RbGeom {
     static constexpr int DWP = 12;                          // depthwise taps of a channel: 9 + bias, padded to 16 bytes
     static constexpr int W_FLOATS = kRbC * kRbC, PAR_FLOATS = 3 * kRbC;
     static constexpr size_t LDS =
-        (size_t)(W_FLOATS + RING * IN_FLOATS + 2 * B_FLOATS + PAR_FLOATS + kRbC * DWP) * sizeof(float);
+        (size_t)(W_FLOATS + 2 * B_FLOATS + PAR_FLOATS + kRbC * DWP) * sizeof(float) + (size_t)RING * IN_BYTES;
     static constexpr int kStores = 64;                      // store instructions per wave and tile
+};
+
+// activation as stored (fp32, or bfloat16 bits widened exactly) -> float
+template <bool BF16> struct RbAct;
+template <> struct RbAct<false> {
+    typedef float T;
+    static __device__ __forceinline__ float widen(float v) { return v; }
+};
+template <> struct RbAct<true> {
+    typedef unsigned short T;
+    static __device__ __forceinline__ float widen(unsigned short v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
 };
 
 constexpr int kRbSentinel = 0x60000000;      // byte offset beyond any sample this kernel accepts (< 0x20000000 bytes)
@@ -102,7 +118,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // 16 bytes per lane from a buffer straight into LDS (lane l lands at lds + 16*l); out-of-range dwords arrive as 0.
 // A plain device function: the 16-byte form only exists for this target, which a kernel template's host-side
 // instantiation cannot see.
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, float* lds, int voff, int soff) {
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, void* lds, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr_rb)lds, 16, voff, soff, 0, 0);
 }
 
@@ -112,16 +128,18 @@ __device__ __forceinline__ void wait_vm_and_lds() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N < 63 ? N : 63) : "memory");
 }
 
-template <int D>
+template <int D, bool BF16>
 __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs a) {
-    using G = RbGeom<D>;
-    constexpr int TCP = G::TCP, BP = G::BP, RING = G::RING, NCH = G::NCH;
+    using G = RbGeom<D, BF16>;
+    using Act = RbAct<BF16>;
+    typedef typename Act::T act_t;
+    constexpr int TCP = G::TCP, BP = G::BP, RING = G::RING, NCH = G::NCH, EB = G::EB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_w = smem;                                      // [32 k-steps][2 tiles][64 lanes] weight operands
-    float* s_in = s_w + G::W_FLOATS;                        // [RING][4 channels][6][TCP] input patches
-    float* s_b = s_in + RING * G::IN_FLOATS;                // [2][4][BP] depthwise results = pixel operands
+    float* s_b = s_w + G::W_FLOATS;                         // [2][4][BP] depthwise results = pixel operands
     float* s_par = s_b + 2 * G::B_FLOATS;                   // [3][64] pointwise bias, BatchNorm scale, shift
     float* s_dw = s_par + G::PAR_FLOATS;                    // [64][12] depthwise taps + bias
+    char* s_in = reinterpret_cast<char*>(s_dw + kRbC * G::DWP);   // [RING][4 channels][6][TCP] input patches, as stored
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -168,33 +186,33 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
         for (int i = 0; i < G::NDI; ++i) {
             const int q = i * 64 + lane;
             const int r = q / G::QPR, qc = q - r * G::QPR;
-            const int grow = row0 - 1 + r, gc = col0 - G::DL + 4 * qc;
-            const bool ok = (unsigned)grow < (unsigned)a.H && gc + 3 >= 0 && gc < a.W;
-            toff[i] = ok ? (grow * a.W + gc) * 4 : kRbSentinel;
+            const int grow = row0 - 1 + r, gc = col0 - G::DL + G::GE * qc;
+            const bool ok = (unsigned)grow < (unsigned)a.H && gc + G::GE - 1 >= 0 && gc < a.W;
+            toff[i] = ok ? (grow * a.W + gc) * EB : kRbSentinel;
         }
     };
     // this wave's channel of (sample n, chunk) -> ring buffer buf; live = false: no such step (empty descriptor)
     auto dma = [&](int n, int chunk, int buf, bool live) {
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(static_cast<const float*>(a.x) + (size_t)n * kRbC * HW), 0, live ? kRbC * HW * 4 : 0,
+            const_cast<char*>(static_cast<const char*>(a.x) + (size_t)n * kRbC * HW * EB), 0, live ? kRbC * HW * EB : 0,
             0x00020000);
-        float* dst = s_in + buf * G::IN_FLOATS + wave * G::CHF;
-        const int soff = (chunk * G::CK + wave) * HW * 4;
+        char* dst = s_in + buf * G::IN_BYTES + wave * G::CHB;
+        const int soff = (chunk * G::CK + wave) * HW * EB;
 #pragma unroll
         for (int i = 0; i < G::NDI; ++i) {
             if ((i + 1) * 64 <= G::NQ || i * 64 + lane < G::NQ)      // the last instruction may be partly masked
-                dma16(rs, dst + i * 256, toff[i], soff);
+                dma16(rs, dst + i * 1024, toff[i], soff);
         }
     };
     // zeros over the columns of this wave's channel patch that lie left or right of the image (border tiles)
-    auto fix_borders = [&](float* pch, int col0) {
+    auto fix_borders = [&](act_t* pch, int col0) {
         const int nleft = G::DL - col0;                      // columns [0, nleft) are left of the image
         if (nleft > 0) {
             const int c = lane & 15;
 #pragma unroll
             for (int r0 = 0; r0 < G::PROWS; r0 += 4) {
                 const int r = r0 + (lane >> 4);
-                if (r < G::PROWS && c < nleft) pch[r * TCP + c] = 0.f;
+                if (r < G::PROWS && c < nleft) pch[r * TCP + c] = 0;
             }
         }
         const int cr0 = a.W - col0 + G::DL;                 // columns [cr0, TCP) are right of the image
@@ -203,14 +221,14 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
 #pragma unroll
             for (int r0 = 0; r0 < G::PROWS; r0 += 2) {
                 const int r = r0 + (lane >> 5);
-                if (c < TCP) pch[r * TCP + c] = 0.f;
+                if (c < TCP) pch[r * TCP + c] = 0;
             }
         }
     };
 
     // depthwise 3x3, dilation (1, D), of this wave's channel of a chunk (global channel chg): ring buffer -> B buffer
     struct DwIn { float k[9], bias, v[G::PROWS][3]; };
-    auto dw_load = [&](const float* pch, int chg, DwIn& d) {
+    auto dw_load = [&](const act_t* pch, int chg, DwIn& d) {
         const f32x4 k0 = *reinterpret_cast<const f32x4*>(s_dw + chg * G::DWP);
         const f32x4 k1 = *reinterpret_cast<const f32x4*>(s_dw + chg * G::DWP + 4);
         const f32x2 k2 = *reinterpret_cast<const f32x2*>(s_dw + chg * G::DWP + 8);
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
 #pragma unroll
         for (int r = 0; r < G::PROWS; ++r)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) d.v[r][q] = pch[r * TCP + lane + (G::DL - D) + q * D];
+            for (int q = 0; q < 3; ++q) d.v[r][q] = Act::widen(pch[r * TCP + lane + (G::DL - D) + q * D]);
     };
     auto dw_row = [&](const DwIn& d, float* pb, int r) {
         float o = d.bias;
@@ -264,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
             for (int r = 0; r < 16; ++r) res[t][h][r] = 0.f;
     {
         DwIn d;
-        float* pch = s_in + wave * G::CHF;
+        act_t* pch = reinterpret_cast<act_t*>(s_in + wave * G::CHB);
         fix_borders(pch, col0);
         dw_load(pch, wave, d);
 #pragma unroll
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
                     wv[ks][h] = sw[(ks * 2 + h) * 64];
                 }
             DwIn d;
-            float* pch = s_in + next_rb * G::IN_FLOATS + wave * G::CHF;
+            act_t* pch = reinterpret_cast<act_t*>(s_in + next_rb * G::IN_BYTES + wave * G::CHB);
             if (!RB_OFF(1)) {
                 // On the very last step of the workgroup there is no next step: the depthwise then runs on a
                 // stale patch into a B buffer nobody reads, which costs less than a second code path.
@@ -318,11 +336,12 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
             // ---- the running-add operand of this step's four channels: centre of its patch.  They belong to the
             // lanes of one half (channel = 4*(l>>5) + 8*(r>>2) + (r&3) within a tile of 32). ----
             if (a.residual && half == (p & 1)) {
-                const float* pc = s_in + cur_rb * G::IN_FLOATS + (wave + 1) * TCP + G::DL + j;
+                const act_t* pc = reinterpret_cast<const act_t*>(s_in + cur_rb * G::IN_BYTES) + (wave + 1) * TCP + G::DL + j;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) res[p >> 3][h][4 * ((p & 7) >> 1) + i] = pc[i * G::CHF + h * 32];
+                    for (int h = 0; h < 2; ++h)
+                        res[p >> 3][h][4 * ((p & 7) >> 1) + i] = Act::widen(pc[i * (G::CHB / EB) + h * 32]);
             }
             float* pbn = s_b + (cur ^ 1) * G::B_FLOATS;
 #pragma unroll
@@ -347,14 +366,14 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
 
         // ---- epilogue: PReLU (v + (alpha - 1) * min(v, 0)), BatchNorm affine, running add, store ----
         {
-            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(static_cast<float*>(a.out) + (size_t)n * kRbC * HW, 0,
-                                                                  RB_OFF(8) ? 0 : kRbC * HW * 4, 0x00020000);
+            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(a.out) + (size_t)n * kRbC * HW * EB, 0,
+                                                                  RB_OFF(8) ? 0 : kRbC * HW * EB, 0x00020000);
             const int orow = row0 + wave;
             int obase[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int ocol = col0 + h * 32 + j;
-                obase[h] = (orow < a.H && ocol < a.W) ? ((4 * half) * HW + orow * a.W + ocol) * 4 : kRbSentinel;
+                obase[h] = (orow < a.H && ocol < a.W) ? ((4 * half) * HW + orow * a.W + ocol) * EB : kRbSentinel;
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
                         float v = acc[t][h][r];
                         v = fmaf(fminf(v, 0.f), alpha_m1, v);
                         v = fmaf(v, sc, sh) + res[t][h][r];
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs_out, obase[h], cou * HW * 4, 0);
+                        buf_st_act<BF16>(v, rs_out, obase[h], cou * HW * EB);
                     }
                 }
         }
@@ -378,17 +397,18 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
     }
 }
 
-template <int D>
+template <int D, bool BF16>
 static hipError_t launch_dma_t(hipStream_t s, const ResblockArgs& a, int grid) {
     // dynamic LDS beyond 64 KB has to be allowed per kernel and per device; the call is cheap, so it is made every time
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_dma_kernel<D>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbGeom<D>::LDS);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_dma_kernel<D, BF16>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbGeom<D, BF16>::LDS);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((resblock_dma_kernel<D>), dim3(grid), dim3(256), RbGeom<D>::LDS, s, a);
+    constexpr size_t lds = RbGeom<D, BF16>::LDS;
+    hipLaunchKernelGGL((resblock_dma_kernel<D, BF16>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_resblock_dma(int dilation_w, hipStream_t s, ResblockArgs a) {
+hipError_t launch_resblock_dma(int dilation_w, hipStream_t s, ResblockArgs a, bool bf16) {
     a.tiles_h = (a.H + kRbTR - 1) / kRbTR;
     a.tiles_w = (a.W + 63) / 64;
     const long long nt = (long long)a.N * a.tiles_h * a.tiles_w;
@@ -399,11 +419,11 @@ hipError_t launch_resblock_dma(int dilation_w, hipStream_t s, ResblockArgs a) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = (int)(nt < 2ll * cus ? nt : 2ll * cus);
     switch (dilation_w) {
-        case 1: return launch_dma_t<1>(s, a, grid);
-        case 2: return launch_dma_t<2>(s, a, grid);
-        case 4: return launch_dma_t<4>(s, a, grid);
-        case 8: return launch_dma_t<8>(s, a, grid);
-        case 16: return launch_dma_t<16>(s, a, grid);
+        case 1: return bf16 ? launch_dma_t<1, true>(s, a, grid) : launch_dma_t<1, false>(s, a, grid);
+        case 2: return bf16 ? launch_dma_t<2, true>(s, a, grid) : launch_dma_t<2, false>(s, a, grid);
+        case 4: return bf16 ? launch_dma_t<4, true>(s, a, grid) : launch_dma_t<4, false>(s, a, grid);
+        case 8: return bf16 ? launch_dma_t<8, true>(s, a, grid) : launch_dma_t<8, false>(s, a, grid);
+        case 16: return bf16 ? launch_dma_t<16, true>(s, a, grid) : launch_dma_t<16, false>(s, a, grid);
         default: return hipErrorInvalidValue;
     }
 }
