@@ -289,3 +289,53 @@ def test_bench_refuses_world_size_mismatch():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
                          env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr
+
+
+def test_every_entry_point_is_a_dispatcher_op_with_shape_inference():
+    """The training, recurrence and blocked-layout entry points are torch.ops.unetmi.* ops like the forward ones:
+    under FakeTensorMode (no device, no kernel) each returns tensors of the shapes and dtypes the HIP path gives."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import unet_amd  # noqa: F401  (registers the ops)
+    ops = torch.ops.unetmi
+    geom = [4, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0]
+    with FakeTensorMode():
+        z, c = torch.empty(2, 8, 5, 7), torch.empty(8)
+        mean, invstd = ops.bn_train_stats(z, 1e-5, 0.1, c, c.clone())
+        assert mean.shape == invstd.shape == (8,)
+        assert ops.bn_act_fwd(z, mean, invstd, c, c, 1, None).shape == z.shape
+        dz, dg, db, dbias = ops.bn_act_bwd(z, z, mean, invstd, c, c, 1, None, True)
+        assert dz.shape == z.shape and dg.shape == db.shape == dbias.shape == (8,)
+        assert ops.conv2d_wgrad(z, None, torch.empty(2, 4, 5, 7), geom, [0, 0]).shape == (4, 8, 3, 3)
+        assert ops.conv2d_wgrad(z, None, torch.empty(2, 4, 5, 7), geom, [1, 0]).shape == (8, 4, 3, 3)
+        status = ops.lstm_recurrence(torch.empty(2560, 640), torch.empty(5, 2560, 16), torch.empty(6, 640, 16), True)
+        assert status.shape == () and status.dtype == torch.int32
+        b = ops.blocked_from_nchw(z)
+        assert b.shape == (2, 2, 5, 7, 8) and b.dtype == torch.bfloat16
+        assert ops.nchw_from_blocked(b, 8, True).dtype == torch.float32
+        w = torch.empty(10, dtype=torch.int16)
+        assert ops.conv2d_b16_fwd(b, 8, None, 0, w, c, c, c, None, None, geom, [0, 0, 0, 1, 0]).shape == (2, 2, 5, 7, 8)
+        out = ops.conv2d_b16_fwd(b, 8, None, 0, w, c, c, c, None, None, geom, [0, 0, 0, 1, 1])
+        assert out.shape == (2, 4, 5, 7) and out.dtype == torch.float32
+        assert ops.adam_step(c, c, c, c, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 1) is None
+
+
+def test_blocked_conv_folds_only_eval_batchnorm_and_handles_affine_false():
+    import pytest
+    import torch
+    import torch.nn as nn
+    from unet_amd.blocked import BlockedConv
+    conv = nn.Conv2d(16, 32, (3, 3), padding=1)
+    bn = nn.BatchNorm2d(32, affine=False)
+    bn.running_mean.uniform_(-1, 1)
+    bn.running_var.uniform_(0.5, 2)
+    layer = BlockedConv(conv, bn, nn.ReLU())
+    with pytest.raises(NotImplementedError):           # train mode: batch statistics cannot be folded
+        layer._prepare(16, 0, torch.device("cpu"))
+    bn.eval()
+    st = layer._prepare(16, 0, torch.device("cpu"))
+    scale = torch.rsqrt(bn.running_var + bn.eps)
+    assert torch.equal(st["scale"], scale) and torch.equal(st["shift"], -bn.running_mean * scale)
+    untracked = nn.BatchNorm2d(32, track_running_stats=False).eval()
+    with pytest.raises(NotImplementedError):
+        BlockedConv(conv, untracked, nn.ReLU())._prepare(16, 0, torch.device("cpu"))

@@ -431,9 +431,10 @@ class DSUNet_helper(nn.Module):
         feat_src = X
         if self.corr:
             feat_src = torch.cat([X[:, :1], X[:, :1] * X[:, 1:]], dim=1)
-        SV = self.steering_vector(angle, mic_pos)
+        # angle / mic_pos may live on the host (no device wait for the path-length differences then)
+        SV = self.steering_vector(angle, mic_pos, x.device)
         SV = torch.cat((SV.real, SV.imag), -1)
-        theta = self.anlge_pre(angle)
+        theta = self.anlge_pre(angle.to(x.device, non_blocking=True))
         parts = [feat_src.real, feat_src.imag]
         if self.DSB:
             dsb = self.delay_n_sum(feat_src, angle, mic_pos)
@@ -449,11 +450,17 @@ class DSUNet_helper(nn.Module):
         rad = (-angle) / 180 * torch.pi
         return torch.stack((torch.sin(rad), torch.cos(rad)), 1)
 
-    def _tdoa(self, angle, mic_pos):
-        """Path-length differences [B, C].  Computed on the HOST with the reference's own operations
+    def _tdoa(self, angle, mic_pos, device):
+        """Path-length differences [B, C] on ``device``.  Computed on the HOST with the reference's own operations
         (DSUNet.py:741-750): they are differences of ~100 m distances, so one fp32 ulp of a distance moves the
         phase at the top bin by 1e-3 rad -- a device reduction that rounds the norm differently would show up at
-        that level in the beamformer channel.  Twelve numbers per call."""
+        that level in the beamformer channel.  Twelve numbers per call: pass ``angle`` / ``mic_pos`` as host tensors
+        and nothing waits for the device; device tensors cost one synchronising copy, paid once per
+        (tensor, version) pair because the result is cached."""
+        key = (angle.data_ptr(), angle._version, mic_pos.data_ptr(), mic_pos._version, str(angle.device), str(device))
+        hit = getattr(self, "_tdoa_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
         ang = angle.detach().float().cpu()
         mp = mic_pos.detach().float().cpu()
         B = ang.shape[0]
@@ -464,18 +471,21 @@ class DSUNet_helper(nn.Module):
         tdoa = torch.zeros(B, self.n_channel)
         for i in range(self.n_channel):
             tdoa[:, i] = torch.norm(mp[:, i] - loc_src)     # one norm over the whole [B,3] difference, as in the reference
-        return (tdoa[:, :] - tdoa[:, 0:1]).to(angle.device)
+        out = (tdoa[:, :] - tdoa[:, 0:1]).to(device, non_blocking=True)
+        self._tdoa_cache = (key, out)
+        return out
 
-    def _phasors(self, angle, mic_pos, sign):
-        tdoa = self._tdoa(angle, mic_pos)                                                     # [B, C]
+    def _phasors(self, angle, mic_pos, sign, device=None):
+        device = angle.device if device is None else device
+        tdoa = self._tdoa(angle, mic_pos, device)                                             # [B, C]
         const = sign * 2 * torch.pi * self.sr / (self.n_fft * self.ss)
-        j = torch.arange(self.n_hfft, device=angle.device, dtype=torch.float32)
+        j = torch.arange(self.n_hfft, device=device, dtype=torch.float32)
         phase = tdoa[:, :, None] * j[None, None, :] * const                                   # [B, C, F]
         out = torch.polar(torch.ones_like(phase), phase)
         return out / torch.linalg.norm(out, dim=1, keepdim=True)
 
-    def steering_vector(self, angle, mic_pos):
-        return self._phasors(angle, mic_pos, -1)
+    def steering_vector(self, angle, mic_pos, device=None):
+        return self._phasors(angle, mic_pos, -1, device)
 
     def delay_n_sum(self, X, angle, mic_pos):
-        return torch.einsum("bcft,bcf->bft", X, self._phasors(angle, mic_pos, +1))
+        return torch.einsum("bcft,bcf->bft", X, self._phasors(angle, mic_pos, +1, X.device))

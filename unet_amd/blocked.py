@@ -18,8 +18,7 @@ from .ops import conv_out_size, make_desc, set_launch_observer  # noqa: F401
 from . import ops as _ops
 
 
-def blocks_for(C):
-    return 2 * ((C + 15) // 16)
+blocks_for = _ops.blocks_for
 
 
 class BlockedTensor:
@@ -36,23 +35,12 @@ class BlockedTensor:
     @staticmethod
     def from_nchw(x):
         """x: contiguous fp32 or bfloat16 device tensor [N,C,H,W]."""
-        if not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
-            raise ValueError("BlockedTensor.from_nchw: contiguous 4-D device tensor expected")
-        N, C, H, W = x.shape
-        out = torch.empty((N, blocks_for(C), H, W, 8), dtype=torch.bfloat16, device=x.device)
-        with torch.cuda.device(x.device):
-            check(_lib.lib.unetmi_blocked_from_nchw(N, C, H * W, x.data_ptr(), _ops.dtype_code(x), out.data_ptr(),
-                                                    torch.cuda.current_stream().cuda_stream), "unetmi_blocked_from_nchw")
-        return BlockedTensor(out, C)
+        return BlockedTensor(_ops.blocked_from_nchw(x), x.shape[1])
 
     def to_nchw(self, dtype=torch.bfloat16):
-        N, C, H, W = self.shape
-        out = torch.empty((N, C, H, W), dtype=dtype, device=self.data.device)
-        code = _lib.DTYPE_BF16 if dtype == torch.bfloat16 else _lib.DTYPE_F32
-        with torch.cuda.device(out.device):
-            check(_lib.lib.unetmi_nchw_from_blocked(N, C, H * W, self.data.data_ptr(), out.data_ptr(), code,
-                                                    torch.cuda.current_stream().cuda_stream), "unetmi_nchw_from_blocked")
-        return out
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("BlockedTensor.to_nchw: bfloat16 or float32")
+        return _ops.nchw_from_blocked(self.data, self.C, dtype == torch.float32)
 
 
 def _geom_of(conv):
@@ -65,12 +53,7 @@ def _geom_of(conv):
     return [conv.out_channels, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw], int(transposed)
 
 
-def _desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, has_gate, halves, nchw_out):
-    d = make_desc(N, C0, C1, H, W, geom, [transposed, _lib.IN_CONCAT if C1 else _lib.IN_SINGLE, act, act_first],
-                  act_pc, has_gate, 0, _lib.DTYPE_BF16)
-    d.reserved[1] = halves
-    d.reserved[2] = int(nchw_out)
-    return d
+_desc = _ops.b16_desc
 
 
 def pack_b16_weights(weight, C0, C1, geom, transposed, halves=1):
@@ -87,48 +70,12 @@ def pack_b16_weights(weight, C0, C1, geom, transposed, halves=1):
 
 def conv2d_b16(x, skip, wpacked, bias, scale, shift, act_param, gate, geom, transposed, act, act_first=0,
                halves=1, nchw_out=False):
-    """One launch.  x, skip: BlockedTensor (skip may be None); returns a BlockedTensor, or with
-    ``nchw_out`` a plain fp32 [N,K,OH,OW] tensor."""
-    N, C0, H, W = x.shape
-    C1 = 0
-    if skip is not None:
-        if skip.data.shape[0] != N or tuple(skip.data.shape[2:4]) != (H, W):
-            raise ValueError("conv2d_b16: skip {} does not match x {}".format(skip.shape, x.shape))
-        C1 = skip.C
-    K = geom[0]
-    act_pc = 1 if (act_param is not None and act_param.numel() > 1) else 0
-    d = _desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, int(gate is not None), halves, nchw_out)
-    expect = _lib.lib.unetmi_conv2d_b16_packed_weight_bytes(ctypes.byref(d))
-    if expect == 0:
-        raise _lib.UnetmiError("conv2d_b16: " + _lib.last_error(), _lib.E_BAD_DESC)
-    if wpacked.numel() * wpacked.element_size() != expect:
-        raise ValueError("conv2d_b16: packed weight image has {} bytes, expected {}".format(
-            wpacked.numel() * wpacked.element_size(), expect))
-    for t, name in ((bias, "bias"), (scale, "scale"), (shift, "shift")):
-        if not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != (K,) or not t.is_contiguous():
-            raise ValueError("conv2d_b16: {} must be a contiguous fp32 device tensor [K]".format(name))
-    if gate is not None and (tuple(gate.shape) != (N, K) or gate.dtype != torch.float32 or not gate.is_contiguous()):
-        raise ValueError("conv2d_b16: gate must be a contiguous fp32 [N,K] tensor")
-    dev = x.data.device
-    if nchw_out:
-        out = torch.empty((N, K, d.OH, d.OW), dtype=torch.float32, device=dev)
-    else:
-        out = torch.empty((N, blocks_for(K), d.OH, d.OW, 8), dtype=torch.bfloat16, device=dev)
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream().cuda_stream
-        obs = _ops._launch_observer
-        if obs is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        check(_lib.lib.unetmi_conv2d_b16_fwd(ctypes.byref(d), x.data.data_ptr(), None if skip is None else skip.data.data_ptr(),
-                                             wpacked.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                             None if act_param is None else act_param.data_ptr(),
-                                             None if gate is None else gate.data_ptr(), out.data_ptr(), stream),
-              "unetmi_conv2d_b16_fwd")
-        if obs is not None:
-            ev1.record()
-            obs("conv2d_b16_fwd", d, ev0, ev1)
-    return out if nchw_out else BlockedTensor(out, K)
+    """One launch (torch.ops.unetmi.conv2d_b16_fwd).  x, skip: BlockedTensor (skip may be None); returns a
+    BlockedTensor, or with ``nchw_out`` a plain fp32 [N,K,OH,OW] tensor."""
+    out = _ops.conv2d_b16_fwd(x.data, x.C, None if skip is None else skip.data, 0 if skip is None else skip.C, wpacked,
+                              bias, scale, shift, act_param, gate, list(geom),
+                              [int(transposed), int(act), int(act_first), int(halves), int(nchw_out)])
+    return out if nchw_out else BlockedTensor(out, geom[0])
 
 
 class BlockedConv:
@@ -157,7 +104,7 @@ class BlockedConv:
         return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
 
     def _prepare(self, C0, C1, device):
-        key = (self._versions(), str(device))
+        key = (self._versions(), str(device), self.norm is not None and self.norm.training)
         if key != self._key:
             self._img.clear()
             self._key = key
@@ -169,8 +116,15 @@ class BlockedConv:
         bias = self.conv.bias.detach().to(**f32) if self.conv.bias is not None else torch.zeros(K, **f32)
         if self.norm is not None:
             n = self.norm
-            scale = (n.weight.detach().to(**f32) / torch.sqrt(n.running_var.detach().to(**f32) + n.eps))
-            shift = n.bias.detach().to(**f32) - n.running_mean.detach().to(**f32) * scale
+            if n.training or n.running_mean is None or n.running_var is None:
+                raise NotImplementedError("BlockedConv folds BatchNorm2d from its running statistics: the norm must be "
+                                          "in eval() mode and track them")
+            scale = torch.rsqrt(n.running_var.detach().to(**f32) + n.eps)
+            if n.weight is not None:                     # affine=False: no weight / bias
+                scale = n.weight.detach().to(**f32) * scale
+            shift = -n.running_mean.detach().to(**f32) * scale
+            if n.bias is not None:
+                shift = shift + n.bias.detach().to(**f32)
         else:
             scale, shift = torch.ones(K, **f32), torch.zeros(K, **f32)
         if isinstance(self.act_src, torch.Tensor):

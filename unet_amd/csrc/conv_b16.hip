@@ -572,11 +572,6 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     };
     const size_t par_bytes = 5 * pl->MT * 32 * 4;
     const bool general_act = d.act != UNETMI_ACT_NONE && d.act != UNETMI_ACT_LEAKY && d.act != UNETMI_ACT_RELU;
-    int force_nt = 0, force_occ = -1;
-    if (const char* e = std::getenv("UNETMI_B16_MODE")) {     // "nt,occ2" for experiments, e.g. "2,0"
-        force_nt = e[0] - '0';
-        if (e[1] == ',' && e[2]) force_occ = e[2] - '0';
-    }
     bool found = false;
     for (int cc = allrows_ok ? 0 : 6; cc < 12 && !found; ++cc) {      // first with whole-group steps, then without
         const int c = cc % 6;                       // 4, 5: one workgroup per CU with rings of 2 (large steps)
@@ -589,8 +584,6 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         if (nt == 2 && pl->MT > 3) continue;
         if (a.pair && nt != 2) continue;
         if (occ2 && general_act) continue;
-        if (force_nt && nt != force_nt && !a.pair) continue;
-        if (force_occ >= 0 && (int)occ2 != force_occ) continue;
         const size_t ib = in_bytes(nt);
         const int din = (occ2 || shallow) ? 1 : (single_step_group ? 2 : 1);
         const int wring = (occ2 || shallow) ? 2 : 3;
@@ -625,13 +618,12 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
 }
 
 template <typename Kernel>
-static hipError_t launch_b16(Kernel kernel, bool* raised, const B16Plan& pl, hipStream_t stream) {
-    if (!*raised) {                    // dynamic LDS beyond 64 KB has to be requested once per kernel
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        *raised = true;
-    }
+static hipError_t launch_b16(Kernel kernel, PerDeviceLatch* raised, const B16Plan& pl, hipStream_t stream) {
+    const hipError_t e = raised->once([kernel] {       // dynamic LDS beyond 64 KB: once per kernel and device
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
     return hipGetLastError();
 }
@@ -712,15 +704,15 @@ int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* 
                                               "and not for time-stride-2 transposed layers");
 #define UNETMI_B16(MT_, NT_, GEN_)                                                                          \
     if (!pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && gen == GEN_ && !pl.occ2) {                         \
-        static bool raised = false; e = launch_b16(&conv_b16_kernel<MT_, NT_, GEN_>, &raised, pl, st); }
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel<MT_, NT_, GEN_>, &raised, pl, st); }
 #define UNETMI_B16_OCC2(MT_, NT_)                                                                           \
     if (!pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && !gen && pl.occ2) {                                 \
-        static bool raised = false; e = launch_b16(&conv_b16_kernel_occ2<MT_, NT_>, &raised, pl, st); }
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_occ2<MT_, NT_>, &raised, pl, st); }
 #define UNETMI_B16_PAIR(MT_)                                                                                \
     if (pl.args.pair && pl.MT == MT_ && !pl.occ2) {                                                         \
-        static bool raised = false; e = launch_b16(&conv_b16_kernel_pair<MT_>, &raised, pl, st); }          \
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair<MT_>, &raised, pl, st); }          \
     if (pl.args.pair && pl.MT == MT_ && pl.occ2) {                                                          \
-        static bool raised = false; e = launch_b16(&conv_b16_kernel_pair_occ2<MT_>, &raised, pl, st); }
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair_occ2<MT_>, &raised, pl, st); }
     UNETMI_B16(1, 1, false) UNETMI_B16(1, 2, false) UNETMI_B16(2, 1, false) UNETMI_B16(2, 2, false)
     UNETMI_B16(3, 1, false) UNETMI_B16(3, 2, false) UNETMI_B16(4, 1, false)
     UNETMI_B16(1, 1, true) UNETMI_B16(1, 2, true)

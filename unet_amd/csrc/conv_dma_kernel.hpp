@@ -202,12 +202,12 @@ __global__ __launch_bounds__(256, NG == 1 ? 3 : 2) void conv_dma_kernel(const Co
 
 template <int NG, int TPG, int WM, int WN, int NTW0, int NTW1>
 inline void launch_dma_variant(unsigned grid, size_t lds, hipStream_t stream, const ConvArgs& p) {
-    static bool raised = false;        // dynamic LDS beyond 64 KB has to be requested once per kernel
-    if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<NG, TPG, WM, WN, NTW0, NTW1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        raised = true;
-    }
+    static PerDeviceLatch raised;      // dynamic LDS beyond 64 KB: once per kernel and device
+    // a failure here shows up as the launch error the caller reads with hipGetLastError()
+    (void)raised.once([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<NG, TPG, WM, WN, NTW0, NTW1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    });
     hipLaunchKernelGGL((conv_dma_kernel<NG, TPG, WM, WN, NTW0, NTW1>), dim3(grid), dim3(256), lds, stream, p);
 }
 

@@ -31,12 +31,16 @@
 
 namespace unetmi {
 
+// Developer probes (tools/conv_probe.hip builds with -DUNETMI_ABLATE); the library itself has no mutable state.
 #ifdef UNETMI_ABLATE
 int g_ablate = 0;
 unsigned long long* g_stamps = nullptr;
+int g_force_staged = 0;  // 1: always use the register-staged kernel
+int g_xcd_remap = 0;     // 1: one XCD walks a contiguous run of tiles
+#else
+constexpr int g_force_staged = 0;
+constexpr int g_xcd_remap = 0;
 #endif
-int g_force_staged = 0;  // 1: always use the register-staged kernel (developer probe)
-int g_xcd_remap = -1;   // -1: per-layer default; 0/1: forced (developer probe)
 
 static unsigned magic_u32(int d) {
     return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d);
@@ -69,7 +73,7 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
     p.nrows = pl.nrows; p.ncols = pl.ncols; p.plane = pl.plane;
     p.in_tile_floats = pl.in_tile_floats; p.w_tile_floats = pl.w_tile_floats; p.njt = pl.njt;
     p.magic_ncols = magic_u32(pl.ncols); p.magic_nrows = magic_u32(pl.nrows);
-    p.xcd_remap = g_xcd_remap >= 0 ? g_xcd_remap : 0;
+    p.xcd_remap = g_xcd_remap;
     p.bf16 = d.reserved[0] == UNETMI_DTYPE_BF16;
 #ifdef UNETMI_ABLATE
     p.ablate = g_ablate;

@@ -4,7 +4,29 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 namespace unetmi {
+
+// A kernel attribute (dynamic LDS beyond 64 KB) has to be raised once per kernel AND per device.  One of these per
+// kernel instantiation: a bit per device ordinal, set after the attribute call succeeded on that device.  Two
+// threads racing on the first launch both make the (idempotent) call; nobody launches before it has succeeded.
+struct PerDeviceLatch {
+    std::atomic<unsigned long long> done[4] = {};      // 256 device ordinals
+    template <class F>
+    hipError_t once(F&& raise) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if ((unsigned)dev >= 256u) return raise();
+        std::atomic<unsigned long long>& word = done[dev >> 6];
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (word.load(std::memory_order_acquire) & bit) return hipSuccess;
+        e = raise();
+        if (e == hipSuccess) word.fetch_or(bit, std::memory_order_release);
+        return e;
+    }
+};
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __builtin_bit_cast(float, (unsigned)b << 16);

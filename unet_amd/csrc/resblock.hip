@@ -266,13 +266,12 @@ static hipError_t launch_resblock_t(int grid, hipStream_t s, const ResblockArgs&
     constexpr int kRbCK = DWISE ? 8 : 16;
     constexpr int NSLOT = (kRbCK * (kRbTR + (DWISE ? 2 : 0)) * (TC + 2 * D) + 255) / 256;
     constexpr size_t lds = (size_t)((DWISE ? NSLOT * 256 : 0) + kRbCK * (kRbTR * TC + 32) + kRbC * kRbC + 3 * kRbC + 10 * kRbC) * sizeof(float);
-    static bool raised = false;                     // dynamic LDS beyond 64 KB is requested once per kernel
-    if (!raised) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_layer_kernel<D, DWISE, BF16, TC>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    static PerDeviceLatch raised;                   // dynamic LDS beyond 64 KB: once per kernel and device
+    const hipError_t e = raised.once([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_layer_kernel<D, DWISE, BF16, TC>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((resblock_layer_kernel<D, DWISE, BF16, TC>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }

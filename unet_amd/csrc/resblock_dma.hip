@@ -399,9 +399,11 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
 
 template <int D, bool BF16>
 static hipError_t launch_dma_t(hipStream_t s, const ResblockArgs& a, int grid) {
-    // dynamic LDS beyond 64 KB has to be allowed per kernel and per device; the call is cheap, so it is made every time
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_dma_kernel<D, BF16>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbGeom<D, BF16>::LDS);
+    static PerDeviceLatch raised;                   // dynamic LDS beyond 64 KB: once per kernel and device
+    const hipError_t e = raised.once([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_dma_kernel<D, BF16>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbGeom<D, BF16>::LDS);
+    });
     if (e != hipSuccess) return e;
     constexpr size_t lds = RbGeom<D, BF16>::LDS;
     hipLaunchKernelGGL((resblock_dma_kernel<D, BF16>), dim3(grid), dim3(256), lds, s, a);

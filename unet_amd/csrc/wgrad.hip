@@ -23,6 +23,7 @@
 #include <string>
 
 #include "../../include/unetmi.h"
+#include "io_types.hpp"
 
 namespace unetmi {
 
@@ -291,13 +292,12 @@ static int plan_wgrad(int N, int A0, int A1, int B, int PH, int PW, int QH, int 
 
 template <int NT>
 static hipError_t launch_wgrad(const WgradPlan& pl, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static PerDeviceLatch raised;                   // dynamic LDS beyond 64 KB: once per kernel and device
+    const hipError_t e = raised.once([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((wgrad_kernel<NT>), dim3(pl.splits, pl.bgroups, pl.ablocks), dim3(256), pl.lds_bytes, s, pl.a);
     return hipGetLastError();
 }

@@ -9,8 +9,7 @@ layer (unetmi_lstm_recurrence) instead of three launches per time step.
 import torch
 import torch.nn as nn
 
-from . import _lib
-from ._lib import check
+from . import ops as _ops
 
 MAX_BATCH_PER_LAUNCH = 64          # device-wide-barrier kernel (unetmi_lstm_recurrence)
 XCD_BATCH_PER_LAUNCH = 32          # XCD-local kernel (unetmi_lstm_recurrence_xcd): 8 XCDs x 4 batch columns
@@ -43,23 +42,10 @@ def _xcd_kernel_fits(dev):
     return KERNEL == "xcd" and torch.cuda.get_device_properties(dev).multi_processor_count == 256
 
 
-def _recurrence(T, BP, H, wrec, gx, hfull, scratch, use_xcd):
-    """One layer's T dependent steps; returns the kernel's status word (a device scalar, non-zero = aborted)."""
-    stream = torch.cuda.current_stream().cuda_stream
-    if use_xcd:
-        nbytes = _lib.lib.unetmi_lstm_recurrence_xcd_workspace_bytes()
-        ws = scratch.get("xcd")
-        if ws is None or ws.device != gx.device:
-            ws = scratch["xcd"] = torch.empty(nbytes // 4, dtype=torch.int32, device=gx.device)
-        check(_lib.lib.unetmi_lstm_recurrence_xcd(T, BP, H, wrec.data_ptr(), gx.data_ptr(), hfull.data_ptr(),
-                                                  ws.data_ptr(), nbytes, stream), "unetmi_lstm_recurrence_xcd")
-        return ws[8]
-    sync = scratch.get("grid")
-    if sync is None or sync.device != gx.device:
-        sync = scratch["grid"] = torch.empty(H // 4 + 1, dtype=torch.int32, device=gx.device)
-    check(_lib.lib.unetmi_lstm_recurrence(T, BP, H, wrec.data_ptr(), gx.data_ptr(), hfull.data_ptr(),
-                                          sync.data_ptr(), stream), "unetmi_lstm_recurrence")
-    return sync[-1]
+def _recurrence(wrec, gx, hfull, use_xcd):
+    """One layer's T dependent steps (torch.ops.unetmi.lstm_recurrence); returns the kernel's status word
+    (a device scalar, non-zero = aborted)."""
+    return _ops.lstm_recurrence(wrec, gx, hfull, bool(use_xcd))
 
 
 def lstm_forward(lstm, x, cache):
@@ -80,7 +66,6 @@ def lstm_forward(lstm, x, cache):
         seq = torch.zeros((T, x.shape[2], BP), dtype=torch.float32, device=dev)      # [T, in, BP]
         seq[:, :, :B] = x.permute(1, 2, 0)
         aborted = torch.zeros((), dtype=torch.int32, device=dev)
-        scratch = {}
         for layer in range(lstm.num_layers):
             w_ih = getattr(lstm, "weight_ih_l{}".format(layer)).detach().float()
             w_hr = getattr(lstm, "weight_hr_l{}".format(layer)).detach().float()
@@ -89,7 +74,7 @@ def lstm_forward(lstm, x, cache):
             wrec = _folded_recurrent_matrix(lstm, layer, cache)
             hfull = torch.empty((T + 1, H, BP), dtype=torch.float32, device=dev)
             hfull[0].zero_()
-            status = _recurrence(T, BP, H, wrec, gx, hfull, scratch, use_xcd)
+            status = _recurrence(wrec, gx, hfull, use_xcd)
             aborted = aborted | status                                                # the kernel's status word, kept on the device
             seq = torch.matmul(w_hr, hfull[1:])                                       # [T, proj, BP] = next layer's input
         out = seq[:, :, :B].permute(2, 0, 1).contiguous()

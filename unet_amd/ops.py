@@ -342,3 +342,318 @@ crf_apply = torch.ops.unetmi.crf_apply
 resblock_layer = torch.ops.unetmi.resblock_layer
 pwconv64 = torch.ops.unetmi.pwconv64
 glu = torch.ops.unetmi.glu
+
+
+# ---------------------------------------------------------------------------------------
+# training entry points (csrc/bn_train.hip, csrc/wgrad.hip), the recurrence kernels (csrc/lstm*.hip) and the
+# bf16-operand convolution on the blocked layout (csrc/conv_b16.hip)
+# ---------------------------------------------------------------------------------------
+_LIBRARY.define("bn_train_stats(Tensor z, float eps, float momentum, Tensor(a!) running_mean, Tensor(b!) running_var)"
+                " -> (Tensor, Tensor)")
+_LIBRARY.define("bn_act_fwd(Tensor z, Tensor mean, Tensor invstd, Tensor gamma, Tensor beta, int act, Tensor? act_param)"
+                " -> Tensor")
+_LIBRARY.define("bn_act_bwd(Tensor dy, Tensor z, Tensor mean, Tensor invstd, Tensor gamma, Tensor beta, int act, "
+                "Tensor? act_param, bool batch_stats) -> (Tensor, Tensor, Tensor, Tensor)")
+_LIBRARY.define("conv2d_wgrad(Tensor in0, Tensor? in1, Tensor dout, int[] geom, int[] flags) -> Tensor")
+_LIBRARY.define("adam_step(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, "
+                "float beta2, float eps, float weight_decay, float grad_scale, int step) -> ()")
+_LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool xcd) -> Tensor")
+_LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
+_LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
+_LIBRARY.define("conv2d_b16_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
+                "Tensor shift, Tensor? act_param, Tensor? gate, int[] geom, int[] flags) -> Tensor")
+# conv2d_wgrad flags = [transposed, in_mode]; conv2d_b16_fwd flags = [transposed, act, act_first, halves, nchw_out]
+
+_ws_cache = {}
+
+
+def workspace(device, nbytes):
+    """One growing scratch buffer per device (contents never outlive a launch sequence)."""
+    buf = _ws_cache.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[device] = buf
+    return buf
+
+
+def _nc_hw(z):
+    N, C = z.shape[0], z.shape[1]
+    return N, C, z.numel() // max(N * C, 1)
+
+
+def _bn_train_stats_cuda(z, eps, momentum, running_mean, running_var):
+    _dev(z, "z", "bn_train_stats")
+    N, C, HW = _nc_hw(z)
+    for t, name in ((running_mean, "running_mean"), (running_var, "running_var")):
+        _dev(t, name, "bn_train_stats")
+        if t.numel() != C:
+            raise ValueError("unetmi::bn_train_stats: {} needs {} elements".format(name, C))
+    mean = torch.empty(C, dtype=torch.float32, device=z.device)
+    invstd = torch.empty_like(mean)
+    ws = workspace(z.device, _lib.lib.unetmi_bn_workspace_bytes(N, C, HW))
+    with torch.cuda.device(z.device):
+        check(_lib.lib.unetmi_bn_train_stats(N, C, HW, _ptr(z), eps, momentum, _ptr(running_mean), _ptr(running_var),
+                                             _ptr(mean), _ptr(invstd), _ptr(ws), ws.numel(), _stream(z)),
+              "unetmi_bn_train_stats")
+    return mean, invstd
+
+
+def _bn_act_fwd_cuda(z, mean, invstd, gamma, beta, act, act_param):
+    _dev(z, "z", "bn_act_fwd")
+    N, C, HW = _nc_hw(z)
+    for t, name in ((mean, "mean"), (invstd, "invstd"), (gamma, "gamma"), (beta, "beta")):
+        _dev(t, name, "bn_act_fwd")
+        if t.numel() != C:
+            raise ValueError("unetmi::bn_act_fwd: {} needs {} elements".format(name, C))
+    out = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        check(_lib.lib.unetmi_bn_act_fwd(N, C, HW, _ptr(z), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), act,
+                                         _ptr(act_param), _ptr(out), _stream(z)), "unetmi_bn_act_fwd")
+    return out
+
+
+def _bn_act_bwd_cuda(dy, z, mean, invstd, gamma, beta, act, act_param, batch_stats):
+    _dev(z, "z", "bn_act_bwd")
+    N, C, HW = _nc_hw(z)
+    if dy.shape != z.shape or dy.dtype != torch.float32 or not dy.is_cuda:
+        raise ValueError("unetmi::bn_act_bwd: dy must match z")
+    # dy may be a channel slice of a wider contiguous tensor: same inner strides, larger batch stride
+    inner = tuple(dy.stride()[1:]) == tuple(z.stride()[1:])
+    if not inner or (N > 1 and dy.stride(0) < C * HW):
+        dy = dy.contiguous()
+    batch_stride = dy.stride(0) if N > 1 else C * HW
+    dz = torch.empty_like(z)
+    dgamma, dbeta, dbias = (torch.empty(C, dtype=torch.float32, device=z.device) for _ in range(3))
+    ws = workspace(z.device, _lib.lib.unetmi_bn_workspace_bytes(N, C, HW))
+    with torch.cuda.device(z.device):
+        check(_lib.lib.unetmi_bn_act_bwd(N, C, HW, _ptr(dy), batch_stride, _ptr(z), _ptr(mean), _ptr(invstd),
+                                         _ptr(gamma), _ptr(beta), act, _ptr(act_param), int(batch_stats), _ptr(dz),
+                                         _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ws), ws.numel(), _stream(z)),
+              "unetmi_bn_act_bwd")
+    return dz, dgamma, dbeta, dbias
+
+
+def _wgrad_shape(C, geom, transposed):
+    return (C, geom[0], geom[1], geom[2]) if transposed else (geom[0], C, geom[1], geom[2])
+
+
+def _conv2d_wgrad_cuda(in0, in1, dout, geom, flags):
+    _dev(in0, "in0", "conv2d_wgrad"), _dev(dout, "dout", "conv2d_wgrad")
+    N, C0, H, W = in0.shape
+    C1 = 0
+    if in1 is not None:
+        _dev(in1, "in1", "conv2d_wgrad")
+        C1 = in1.shape[1]
+    desc = make_desc(N, C0, C1, H, W, geom, [flags[0], flags[1], 0, 0])
+    if tuple(dout.shape) != (N, geom[0], desc.OH, desc.OW):
+        raise ValueError("unetmi::conv2d_wgrad: dout is {}, expected {}".format(tuple(dout.shape), (N, geom[0], desc.OH, desc.OW)))
+    dw = torch.empty(_wgrad_shape(C0 + C1, geom, flags[0]), dtype=torch.float32, device=in0.device)
+    nbytes = _lib.lib.unetmi_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
+    if nbytes == 0:
+        raise _lib.UnetmiError("unetmi_conv2d_wgrad: " + _lib.last_error(), _lib.E_UNSUPPORTED)
+    ws = workspace(in0.device, nbytes)
+    with torch.cuda.device(in0.device):
+        check(_lib.lib.unetmi_conv2d_wgrad(ctypes.byref(desc), _ptr(in0), _ptr(in1), _ptr(dout), _ptr(dw), _ptr(ws),
+                                           ws.numel(), _stream(in0)), "unetmi_conv2d_wgrad")
+    return dw
+
+
+def _adam_step_cuda(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        _dev(t, "bucket", "adam_step")
+        if t.numel() != param.numel():
+            raise ValueError("unetmi::adam_step: bucket sizes differ")
+    with torch.cuda.device(param.device):
+        check(_lib.lib.unetmi_adam_step(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), lr,
+                                        beta1, beta2, eps, weight_decay, grad_scale, step, _stream(param)),
+              "unetmi_adam_step")
+
+
+_lstm_scratch = {}
+
+
+def _lstm_recurrence_cuda(wrec, gx, hfull, xcd):
+    """One layer's T dependent steps on gx [T, 4H, BP] (input contributions + bias) with the folded recurrent matrix
+    wrec [4H, H]; fills hfull[1:] ([T+1, H, BP], row 0 = initial state).  Returns the kernel's status word as a
+    device scalar (non-zero: a wait gave up and the remaining steps are NaN)."""
+    for t, name in ((wrec, "wrec"), (gx, "gx"), (hfull, "hfull")):
+        _dev(t, name, "lstm_recurrence")
+    T, G, BP = gx.shape
+    H = G // 4
+    if G != 4 * H or tuple(wrec.shape) != (G, H) or tuple(hfull.shape) != (T + 1, H, BP):
+        raise ValueError("unetmi::lstm_recurrence: wrec [4H,H], gx [T,4H,BP], hfull [T+1,H,BP] expected")
+    key = (gx.device, bool(xcd))
+    with torch.cuda.device(gx.device):
+        stream = _stream(gx)
+        if xcd:
+            nbytes = _lib.lib.unetmi_lstm_recurrence_xcd_workspace_bytes()
+            ws = _lstm_scratch.get(key)
+            if ws is None:
+                ws = _lstm_scratch[key] = torch.empty(nbytes // 4, dtype=torch.int32, device=gx.device)
+            check(_lib.lib.unetmi_lstm_recurrence_xcd(T, BP, H, _ptr(wrec), _ptr(gx), _ptr(hfull), _ptr(ws), nbytes,
+                                                      stream), "unetmi_lstm_recurrence_xcd")
+            return ws[8].clone()
+        sync = _lstm_scratch.get(key)
+        if sync is None or sync.numel() != H // 4 + 1:
+            sync = _lstm_scratch[key] = torch.empty(H // 4 + 1, dtype=torch.int32, device=gx.device)
+        check(_lib.lib.unetmi_lstm_recurrence(T, BP, H, _ptr(wrec), _ptr(gx), _ptr(hfull), _ptr(sync), stream),
+              "unetmi_lstm_recurrence")
+        return sync[-1].clone()
+
+
+def blocks_for(C):
+    return 2 * ((C + 15) // 16)
+
+
+def _blocked_from_nchw_cuda(x):
+    if not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
+        raise ValueError("unetmi::blocked_from_nchw: contiguous 4-D device tensor expected")
+    N, C, H, W = x.shape
+    out = torch.empty((N, blocks_for(C), H, W, 8), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib.unetmi_blocked_from_nchw(N, C, H * W, _ptr(x), dtype_code(x), _ptr(out), _stream(x)),
+              "unetmi_blocked_from_nchw")
+    return out
+
+
+def _nchw_from_blocked_cuda(data, C, f32):
+    _dev(data, "data", "nchw_from_blocked", torch.bfloat16)
+    if data.dim() != 5 or data.shape[4] != 8 or data.shape[1] != blocks_for(C):
+        raise ValueError("unetmi::nchw_from_blocked: data must be [N, 2*ceil(C/16), H, W, 8]")
+    N, _, H, W, _ = data.shape
+    out = torch.empty((N, C, H, W), dtype=torch.float32 if f32 else torch.bfloat16, device=data.device)
+    with torch.cuda.device(data.device):
+        check(_lib.lib.unetmi_nchw_from_blocked(N, C, H * W, _ptr(data), _ptr(out),
+                                                _lib.DTYPE_F32 if f32 else _lib.DTYPE_BF16, _stream(data)),
+              "unetmi_nchw_from_blocked")
+    return out
+
+
+def b16_desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, has_gate, halves, nchw_out):
+    d = make_desc(N, C0, C1, H, W, geom, [transposed, _lib.IN_CONCAT if C1 else _lib.IN_SINGLE, act, act_first],
+                  act_pc, has_gate, 0, _lib.DTYPE_BF16)
+    d.reserved[1] = halves
+    d.reserved[2] = int(nchw_out)
+    return d
+
+
+def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, flags):
+    transposed, act, act_first, halves, nchw_out = flags
+    _dev(x, "x", "conv2d_b16_fwd", torch.bfloat16)
+    if x.dim() != 5 or x.shape[4] != 8 or x.shape[1] != blocks_for(C0):
+        raise ValueError("unetmi::conv2d_b16_fwd: x must be [N, 2*ceil(C0/16), H, W, 8] bfloat16")
+    N, _, H, W, _ = x.shape
+    if skip is not None:
+        _dev(skip, "skip", "conv2d_b16_fwd", torch.bfloat16)
+        if skip.dim() != 5 or skip.shape[0] != N or tuple(skip.shape[2:4]) != (H, W) or skip.shape[1] != blocks_for(C1):
+            raise ValueError("unetmi::conv2d_b16_fwd: skip {} does not match x {}".format(tuple(skip.shape), tuple(x.shape)))
+    elif C1:
+        raise ValueError("unetmi::conv2d_b16_fwd: C1 without a skip tensor")
+    K = geom[0]
+    act_pc = 1 if (act_param is not None and act_param.numel() > 1) else 0
+    d = b16_desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, int(gate is not None), halves, nchw_out)
+    expect = _lib.lib.unetmi_conv2d_b16_packed_weight_bytes(ctypes.byref(d))
+    if expect == 0:
+        raise _lib.UnetmiError("conv2d_b16: " + _lib.last_error(), _lib.E_BAD_DESC)
+    if not wpacked.is_cuda or wpacked.numel() * wpacked.element_size() != expect:
+        raise ValueError("unetmi::conv2d_b16_fwd: packed weight image has {} bytes, expected {} on the device".format(
+            wpacked.numel() * wpacked.element_size(), expect))
+    for t, name in ((bias, "bias"), (scale, "scale"), (shift, "shift")):
+        _dev(t, name, "conv2d_b16_fwd")
+        if tuple(t.shape) != (K,):
+            raise ValueError("unetmi::conv2d_b16_fwd: {} must be [K]".format(name))
+    if act_param is not None:
+        _dev(act_param, "act_param", "conv2d_b16_fwd")
+    if gate is not None:
+        _dev(gate, "gate", "conv2d_b16_fwd")
+        if tuple(gate.shape) != (N, K):
+            raise ValueError("unetmi::conv2d_b16_fwd: gate must be [N,K]")
+    if nchw_out:
+        out = torch.empty((N, K, d.OH, d.OW), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty((N, blocks_for(K), d.OH, d.OW, 8), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        obs = _launch_observer
+        if obs is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        check(_lib.lib.unetmi_conv2d_b16_fwd(ctypes.byref(d), _ptr(x), _ptr(skip), _ptr(wpacked), _ptr(bias), _ptr(scale),
+                                             _ptr(shift), _ptr(act_param), _ptr(gate), _ptr(out), _stream(x)),
+              "unetmi_conv2d_b16_fwd")
+        if obs is not None:
+            ev1.record()
+            obs("conv2d_b16_fwd", d, ev0, ev1)
+    return out
+
+
+for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_act_fwd", _bn_act_fwd_cuda),
+                   ("bn_act_bwd", _bn_act_bwd_cuda), ("conv2d_wgrad", _conv2d_wgrad_cuda),
+                   ("adam_step", _adam_step_cuda), ("lstm_recurrence", _lstm_recurrence_cuda),
+                   ("blocked_from_nchw", _blocked_from_nchw_cuda), ("nchw_from_blocked", _nchw_from_blocked_cuda),
+                   ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda)):
+    _LIBRARY.impl(_name, _fn, "CUDA")
+
+
+@torch.library.register_fake("unetmi::bn_train_stats")
+def _(z, eps, momentum, running_mean, running_var):
+    return z.new_empty((z.shape[1],)), z.new_empty((z.shape[1],))
+
+
+@torch.library.register_fake("unetmi::bn_act_fwd")
+def _(z, mean, invstd, gamma, beta, act, act_param):
+    return torch.empty_like(z)
+
+
+@torch.library.register_fake("unetmi::bn_act_bwd")
+def _(dy, z, mean, invstd, gamma, beta, act, act_param, batch_stats):
+    c = z.new_empty((z.shape[1],))
+    return torch.empty_like(z), c, torch.empty_like(c), torch.empty_like(c)
+
+
+@torch.library.register_fake("unetmi::conv2d_wgrad")
+def _(in0, in1, dout, geom, flags):
+    C = in0.shape[1] + (in1.shape[1] if in1 is not None else 0)
+    return in0.new_empty(_wgrad_shape(C, geom, flags[0]))
+
+
+@torch.library.register_fake("unetmi::adam_step")
+def _(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    return None
+
+
+@torch.library.register_fake("unetmi::lstm_recurrence")
+def _(wrec, gx, hfull, xcd):
+    return gx.new_empty((), dtype=torch.int32)
+
+
+@torch.library.register_fake("unetmi::blocked_from_nchw")
+def _(x):
+    N, C, H, W = x.shape
+    return x.new_empty((N, blocks_for(C), H, W, 8), dtype=torch.bfloat16)
+
+
+@torch.library.register_fake("unetmi::nchw_from_blocked")
+def _(data, C, f32):
+    N, _, H, W, _ = data.shape
+    return data.new_empty((N, C, H, W), dtype=torch.float32 if f32 else torch.bfloat16)
+
+
+@torch.library.register_fake("unetmi::conv2d_b16_fwd")
+def _(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, flags):
+    K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
+    N, _, H, W, _ = x.shape
+    OH, OW = conv_out_size(H, kh, sh, ph, dh, oph, flags[0]), conv_out_size(W, kw, sw, pw, dw, opw, flags[0])
+    if flags[4]:
+        return x.new_empty((N, K, OH, OW), dtype=torch.float32)
+    return x.new_empty((N, blocks_for(K), OH, OW, 8))
+
+
+bn_train_stats = torch.ops.unetmi.bn_train_stats
+bn_act_fwd = torch.ops.unetmi.bn_act_fwd
+bn_act_bwd = torch.ops.unetmi.bn_act_bwd
+conv2d_wgrad = torch.ops.unetmi.conv2d_wgrad
+adam_step = torch.ops.unetmi.adam_step
+lstm_recurrence = torch.ops.unetmi.lstm_recurrence
+blocked_from_nchw = torch.ops.unetmi.blocked_from_nchw
+nchw_from_blocked = torch.ops.unetmi.nchw_from_blocked
+conv2d_b16_fwd = torch.ops.unetmi.conv2d_b16_fwd

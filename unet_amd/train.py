@@ -17,7 +17,6 @@ accumulation).  Parameters and gradients can be flattened into single buckets
 optimizer is one kernel.
 """
 
-import ctypes
 import os
 
 import torch
@@ -27,24 +26,7 @@ from . import _lib
 from ._lib import check
 from .ops import conv2d_fwd, conv_out_size, make_desc, pack_conv_weights
 
-_ws_cache = {}
-
-
-def _workspace(device, nbytes):
-    """One growing scratch buffer per device (contents never outlive a launch sequence)."""
-    buf = _ws_cache.get(device)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[device] = buf
-    return buf
-
-
-def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
-
-
-def _ptr(t):
-    return None if t is None else t.data_ptr()
+from . import ops as _ops
 
 
 def _dense(t, what):
@@ -53,87 +35,31 @@ def _dense(t, what):
 
 
 # ---------------------------------------------------------------------------------------
-# thin wrappers of the C ABI
+# the training entry points: torch.ops.unetmi.* (registered in ops.py), under the names this module's callers use
 # ---------------------------------------------------------------------------------------
 def bn_train_stats(z, eps, momentum, running_mean, running_var):
     """(mean, invstd) of z[N,C,...] over all but the channel axis; running stats updated in place."""
-    _dense(z, "bn_train_stats: z")
-    N, C = z.shape[0], z.shape[1]
-    HW = z.numel() // max(N * C, 1)
-    mean = torch.empty(C, dtype=torch.float32, device=z.device)
-    invstd = torch.empty_like(mean)
-    nbytes = _lib.lib.unetmi_bn_workspace_bytes(N, C, HW)
-    ws = _workspace(z.device, nbytes)
-    with torch.cuda.device(z.device):
-        check(_lib.lib.unetmi_bn_train_stats(N, C, HW, _ptr(z), eps, momentum, _ptr(running_mean), _ptr(running_var),
-                                             _ptr(mean), _ptr(invstd), _ptr(ws), ws.numel(), _stream(z)),
-              "unetmi_bn_train_stats")
-    return mean, invstd
+    return _ops.bn_train_stats(z, eps, momentum, running_mean, running_var)
 
 
 def bn_act_fwd(z, mean, invstd, gamma, beta, act, act_param):
-    _dense(z, "bn_act_fwd: z")
-    N, C = z.shape[0], z.shape[1]
-    HW = z.numel() // max(N * C, 1)
-    out = torch.empty_like(z)
-    with torch.cuda.device(z.device):
-        check(_lib.lib.unetmi_bn_act_fwd(N, C, HW, _ptr(z), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), act,
-                                         _ptr(act_param), _ptr(out), _stream(z)), "unetmi_bn_act_fwd")
-    return out
+    return _ops.bn_act_fwd(z, mean, invstd, gamma, beta, act, act_param)
 
 
 def bn_act_bwd(dy, z, mean, invstd, gamma, beta, act, act_param, batch_stats):
     """(dz, dgamma, dbeta, dbias).  dy may be a channel slice of a wider contiguous tensor."""
-    _dense(z, "bn_act_bwd: z")
-    N, C = z.shape[0], z.shape[1]
-    HW = z.numel() // max(N * C, 1)
-    if dy.shape != z.shape or dy.dtype != torch.float32 or not dy.is_cuda:
-        raise ValueError("bn_act_bwd: dy must match z")
-    inner = tuple(dy.stride()[1:]) == tuple(z.stride()[1:])
-    if not inner or (N > 1 and dy.stride(0) < C * HW):
-        dy = dy.contiguous()
-    batch_stride = dy.stride(0) if N > 1 else C * HW
-    dz = torch.empty_like(z)
-    dgamma, dbeta, dbias = (torch.empty(C, dtype=torch.float32, device=z.device) for _ in range(3))
-    nbytes = _lib.lib.unetmi_bn_workspace_bytes(N, C, HW)
-    ws = _workspace(z.device, nbytes)
-    with torch.cuda.device(z.device):
-        check(_lib.lib.unetmi_bn_act_bwd(N, C, HW, _ptr(dy), batch_stride, _ptr(z), _ptr(mean), _ptr(invstd),
-                                         _ptr(gamma), _ptr(beta), act, _ptr(act_param), int(batch_stats), _ptr(dz),
-                                         _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ws), ws.numel(), _stream(z)),
-              "unetmi_bn_act_bwd")
-    return dz, dgamma, dbeta, dbias
+    return _ops.bn_act_bwd(dy, z, mean, invstd, gamma, beta, act, act_param, bool(batch_stats))
 
 
 def conv2d_wgrad(desc, in0, in1, dout):
     """Weight gradient in torch layout for the layer ``desc`` describes."""
-    for t, n in ((in0, "in0"), (dout, "dout")):
-        _dense(t, "conv2d_wgrad: " + n)
-    if in1 is not None:
-        _dense(in1, "conv2d_wgrad: in1")
-    cin = desc.C0 + desc.C1
-    shape = (cin, desc.K, desc.kh, desc.kw) if desc.transposed else (desc.K, cin, desc.kh, desc.kw)
-    dw = torch.empty(shape, dtype=torch.float32, device=in0.device)
-    nbytes = _lib.lib.unetmi_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
-    if nbytes == 0:
-        raise _lib.UnetmiError("unetmi_conv2d_wgrad: " + _lib.last_error(), _lib.E_UNSUPPORTED)
-    ws = _workspace(in0.device, nbytes)
-    with torch.cuda.device(in0.device):
-        check(_lib.lib.unetmi_conv2d_wgrad(ctypes.byref(desc), _ptr(in0), _ptr(in1), _ptr(dout), _ptr(dw), _ptr(ws),
-                                           ws.numel(), _stream(in0)), "unetmi_conv2d_wgrad")
-    return dw
+    geom = [desc.K, desc.kh, desc.kw, desc.sh, desc.sw, desc.ph, desc.pw, desc.dh, desc.dw, desc.oph, desc.opw]
+    return _ops.conv2d_wgrad(in0, in1, dout, geom, [int(desc.transposed), int(desc.in_mode)])
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
-    for t in (param, grad, exp_avg, exp_avg_sq):
-        _dense(t, "adam_step: bucket")
-        if t.numel() != param.numel():
-            raise ValueError("adam_step: bucket sizes differ")
-    with torch.cuda.device(param.device):
-        check(_lib.lib.unetmi_adam_step(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), lr,
-                                        beta1, beta2, eps, weight_decay, grad_scale, step, _stream(param)),
-              "unetmi_adam_step")
-    torch.autograd.graph.increment_version(param)
+    _ops.adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step)
+    torch.autograd.graph.increment_version(param)      # written through a raw pointer
 
 
 # ---------------------------------------------------------------------------------------
