@@ -3,7 +3,7 @@
 This package is the parity checker for the HIP path in ``unet_amd``: plain
 ``torch.nn`` CPU modules that restate, layer for layer, what the reference's
 ``UNet`` / ``cRFUNet.UNet20`` / ``ResUNet`` / ``ResUNetOnFreq`` / ``ResUNetOnFreq2`` / ``DSUNet`` /
-``UDSS`` and the wave-to-wave helpers compute.  It is imported
+``UDSS`` / ``DAU`` and the wave-to-wave helpers compute.  It is imported
 only by ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 ``bench.py``.  Nothing under ``unet_amd/`` imports it and the product never
 routes a forward through it.
@@ -22,13 +22,13 @@ from .blocks import (Encoder, Decoder, ResBlock, DSEncoder, DSDecoder, Attractor
 from .nets import UNet, UNet20, ResUNet, ResUNetOnFreq, ResUNetOnFreq2, LSTMBlock, DSUNet
 from .tables import unet20_layers, default_unet, dsunet_architecture
 from .masking import crf_apply, resunet_mask_apply, crm_apply
-from .helper import DSUNet_helper, UDSS_helper
-from .udss import UDSS, ComplexConv2d, ComplexConvTranspose2d, ComplexBatchNorm2d
+from .helper import DSUNet_helper, UDSS_helper, DAU_helper
+from .udss import UDSS, DAU, ComplexConv2d, ComplexConvTranspose2d, ComplexBatchNorm2d
 
 __all__ = [
     "Encoder", "Decoder", "ResBlock", "DSEncoder", "DSDecoder", "Attractor",
     "AttractEncoder", "CRM", "CRM_sig", "CRM_soft", "CM", "GConv", "TrGConv", "TGRUBlock", "SEBlock", "MultiScaleConvBlock", "GlobalChannelLayerNorm", "DepthwiseSeparableConv2d", "MEA", "custom_atan2", "UNet", "UNet20", "ResUNet", "ResUNetOnFreq", "ResUNetOnFreq2", "LSTMBlock", "DSUNet",
     "unet20_layers", "default_unet", "dsunet_architecture",
     "crf_apply", "resunet_mask_apply", "crm_apply", "DSUNet_helper",
-    "UDSS", "UDSS_helper", "ComplexConv2d", "ComplexConvTranspose2d", "ComplexBatchNorm2d",
+    "UDSS", "UDSS_helper", "DAU", "DAU_helper", "ComplexConv2d", "ComplexConvTranspose2d", "ComplexBatchNorm2d",
 ]

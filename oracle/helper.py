@@ -136,5 +136,30 @@ class UDSS_helper(DSUNet_helper):
             dsb = torch.unsqueeze(torch.stack((dsb.real, dsb.imag), dim=-1), 1)
             spectral_feature = torch.cat((spectral_feature, dsb), dim=1)
         mask = self.net(spectral_feature, SV, theta)
-        Y = self.net.masking(X[:, 0], mask)
+        Y = self._apply_mask(X[:, 0], mask)
         return torch.istft(Y, n_fft=self.n_fft, window=self.window.to(Y.device), length=L)
+
+    def _apply_mask(self, X0, mask):
+        return self.net.masking(X0, mask)
+
+
+class DAU_helper(UDSS_helper):
+    """Wave-in / wave-out wrapper of ``DAU`` (DTU.py:479-629): the transforms, steering vector, delay-and-sum and
+    feature layout of ``UDSS_helper``; the mask multiplies the reference channel directly (DTU.py:562)."""
+
+    def __init__(self, n_fft=512, complex=True, dropout=0.0, bottleneck="None", model_complexity=45,
+                 type_encoder="Complex", use_SV=True, mag_phase=False, corr=False, DSB=False, activation="LeakyReLU"):
+        nn.Module.__init__(self)
+        from .udss import DAU
+        self.n_fft = n_fft
+        self.n_hfft = n_fft // 2 + 1
+        self.n_channel = 4
+        model_channel = self.n_channel + (1 if DSB else 0)
+        self.complex, self.mag_phase, self.use_SV, self.corr, self.DSB = complex, mag_phase, use_SV, corr, DSB
+        self.net = DAU(input_channels=model_channel, complex=complex, dropout=dropout, bottleneck=bottleneck,
+                       model_complexity=model_complexity, type_encoder=type_encoder, activation=activation)
+        self.sr, self.ss, self.dist = 16000, 340.4, 100
+        self.window = torch.hann_window(self.n_fft)
+
+    def _apply_mask(self, X0, mask):
+        return X0 * mask

@@ -371,3 +371,80 @@ class UDSS(nn.Module):
 
     def masking(self, X, M):
         return self.mask.output(X, M)
+
+
+class DAU(nn.Module):
+    """The directional attractor U-Net of DTU.py:227-378: the same ten gated complex encoders, ten complex
+    decoders and complex 1x1 head as ``UDSS`` (same layer table, DTU.py:380-477), BatchNorm only, bottleneck
+    "None" only, and the mask always ``tanh`` of the head (DTU.py:355-358).  ``type_masking`` only selects the
+    ``masking`` member (Identity for "CRM", the ``MEA`` module for "MEA"), which ``forward`` never calls.
+    The reference's forward also prints the shape of every encoder output and gate; that is not restated."""
+
+    def __init__(self, input_channels=4, n_fft=512, complex=True, model_complexity=45, bottleneck="None",
+                 padding_mode="zeros", type_encoder="Complex", type_masking="CRM", activation="LeakyReLU",
+                 dropout=0.0):
+        super().__init__()
+        if not complex:
+            raise NotImplementedError("the real-valued form of this network is DSUNet")
+        self.bottleneck = bottleneck
+        self.complex = complex
+        self.n_channel = input_channels
+        model_complexity = int(model_complexity // 1.414)
+        print("DAU::complexity {}".format(model_complexity))
+        for k, v in udss_table(model_complexity, input_channels).items():
+            setattr(self, k, v)
+        L = self.model_length = 10
+        self.dropout = dropout
+        if type_encoder != "Complex":
+            raise Exception("Not Implemented")
+        if activation == "PReLU":
+            raise TypeError("PReLU.__init__() got an unexpected keyword argument 'inplace'")     # DTU.py:181
+        encs = [UEncoder(self.enc_channels[i], self.enc_channels[i + 1], kernel_size=self.enc_kernel_sizes[i],
+                         stride=self.enc_strides[i], padding=self.enc_paddings[i], padding_mode=padding_mode,
+                         dropout=dropout, activation=activation, type_norm="BatchNorm2d") for i in range(L)]
+        for i, m in enumerate(encs):
+            self.add_module("encoder{}".format(i), m)
+        decs = [UDecoder(self.dec_channels[i] + self.enc_channels[L - i], self.dec_channels[i + 1],
+                         kernel_size=self.dec_kernel_sizes[i], stride=self.dec_strides[i],
+                         padding=self.dec_paddings[i], output_padding=self.dec_output_paddings[i],
+                         activation=activation) for i in range(L)]
+        for i, m in enumerate(decs):
+            self.add_module("decoder{}".format(i), m)
+        if bottleneck != "None":
+            raise Exception("Not Implemented")
+        self.BTN = nn.Identity()
+        self.Attractor = Attractor(n_ch=4, n_fft=n_fft)
+        self.attractEncoders = [AttractEncoder(n_ch=self.enc_channels[i + 1]) for i in range(L)]
+        for i, m in enumerate(self.attractEncoders):
+            self.add_module("attractEncoder_{}".format(i), m)
+        self.add_module("linear", ComplexConv2d(self.dec_channels[-1], 1, 1))
+        self.padding_mode = padding_mode
+        if type_masking == "CRM":
+            self.masking = nn.Identity()
+        elif type_masking == "MEA":
+            from .blocks import MEA
+            self.masking = MEA()
+        else:
+            raise Exception("Not Implemented")
+        self.dr = nn.Dropout(self.dropout)
+        self.decoders = nn.ModuleList(decs)
+        self.encoders = nn.ModuleList(encs)
+        self.attractors = nn.ModuleList(self.attractEncoders)
+
+    def forward(self, sf, SV, theta):
+        attract = self.Attractor(SV, theta)
+        L = self.model_length
+        skips = []
+        for i, enc in enumerate(self.encoders):
+            skips.append(sf)
+            sf = self.dr(enc(sf))
+            gate = self.attractEncoders[i](attract)
+            sf = torch.reshape(gate, (*gate.shape, 1, 1, 1)) * sf
+        p = self.BTN(sf)
+        for i, dec in enumerate(self.decoders):
+            p = dec(p)
+            if i == L - 1:
+                break
+            p = torch.cat([p, skips[L - 1 - i]], dim=1)
+        mask = torch.squeeze(torch.tanh(self.linear(p)), 1)
+        return mask[..., 0] + 1j * mask[..., 1]

@@ -427,6 +427,58 @@ def main():
         helper_out[label] = y_ref.numpy()
     if out is not None:
         save("udss_helper_eval", **helper_out)
+    # ---------------------------------------------------------------- DAU (DTU.py: the earlier form of UDSS)
+    import contextlib
+    import io
+    import DTU as R_dtu
+    dau_out = {}
+    for label, kw in (("crm", {}), ("mea", dict(type_masking="MEA"))):
+        print("DAU({}), B=2 C=4 F=257 T=16 complex".format(kw))
+        ref = R_dtu.DAU(**kw)
+        seeded_fill_(ref, seed=81)
+        mine = oracle.DAU(**kw)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+        sf = normal("dau/sf", (2, 4, 257, 16, 2), seed=81)
+        SV = normal("dau/SV", (2, 4, 514), seed=81)
+        ang = uniform("dau/theta", (2,), 0.0, 2 * np.pi, seed=81)
+        theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+        ref.eval(), mine.eval()
+        with torch.no_grad():
+            with contextlib.redirect_stdout(io.StringIO()):        # the reference's forward prints every layer's shape
+                y_ref = ref(sf, SV, theta)
+            y_mine = mine(sf, SV, theta)
+        require_equal(y_ref, y_mine, "DAU " + label)
+        assert tuple(y_ref.shape) == (2, 257, 16) and y_ref.dtype == torch.complex64
+        dau_out[label] = torch.view_as_real(y_ref).numpy()
+    if out is not None:
+        save("dau_eval", **dau_out)
+    print("DAU_helper (STFT -> complex features -> DAU -> mask -> iSTFT), plain and with the beamformer channel, B=2 C=4 L=4000")
+    dau_helper_out = {}
+    for label, kw in (("plain", {}), ("dsb", dict(DSB=True))):
+        ref = R_dtu.DAU_helper(**kw)
+        seeded_fill_(ref, seed=86)
+        mine = oracle.DAU_helper(**kw)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        wav = normal("dau_helper/x", (2, 4, 4000), seed=86) * 0.1
+        angle = uniform("dau_helper/angle", (2,), 0.0, 360.0, seed=86)
+        mic = uniform("dau_helper/mic", (2, 4, 3), -0.05, 0.05, seed=86)
+        ref.eval(), mine.eval()
+        with torch.no_grad():
+            with contextlib.redirect_stdout(io.StringIO()):
+                y_ref = ref(wav, angle, mic)
+            y_mine = mine(wav, angle, mic)
+        require_equal(y_ref, y_mine, "DAU_helper " + label)
+        dau_helper_out[label] = y_ref.numpy()
+    if out is not None:
+        save("dau_helper_eval", **dau_helper_out)
+    for bad in (dict(bottleneck="TGRU"), dict(activation="PReLU"), dict(type_masking="CM")):
+        try:
+            R_dtu.DAU(**bad)
+            fact = "ok"
+        except Exception as e:  # noqa: BLE001
+            fact = type(e).__name__
+        print("  DAU({}) construction: {}".format(bad, fact))
     try:
         R_udss.UDSS()
         udss_default = "ok"

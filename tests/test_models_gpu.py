@@ -199,6 +199,63 @@ def test_udss_matches_golden_and_oracle(device, label, kw):
     assert_close(dev.masking(X.to(device), got), ref.masking(X, want), what="UDSS masking")
 
 
+@pytest.mark.parametrize("label,kw", [("crm", {}), ("mea", dict(type_masking="MEA"))])
+def test_dau_matches_golden_and_oracle(device, label, kw):
+    """DTU.py's DAU: the UDSS layers under the reference's DAU constructor and state_dict keys, mask = tanh of the
+    complex head."""
+    import numpy as np
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.DAU(**kw).eval()
+    unet_amd.seeded_fill_(ref, seed=81)
+    dev = unet_amd.DAU(**kw)
+    assert list(dev.state_dict().keys()) == list(ref.state_dict().keys())
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    sf = normal("dau/sf", (2, 4, 257, 16, 2), seed=81)
+    SV = normal("dau/SV", (2, 4, 514), seed=81)
+    ang = uniform("dau/theta", (2,), 0.0, 2 * np.pi, seed=81)
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    with torch.no_grad():
+        want = ref(sf, SV, theta)
+        got = dev(sf.to(device), SV.to(device), theta.to(device))
+    assert got.dtype == torch.complex64 and tuple(got.shape) == (2, 257, 16)
+    assert_close(got, want, what="DAU {} HIP vs oracle".format(label))
+    assert_close(torch.view_as_real(got.cpu()), torch.from_numpy(load_golden("dau_eval")[label]),
+                 what="DAU {} HIP vs golden".format(label))
+    with pytest.raises(NotImplementedError):
+        dev.train()(sf.to(device), SV.to(device), theta.to(device))
+    for bad, exc in ((dict(bottleneck="TGRU"), Exception), (dict(activation="PReLU"), TypeError)):
+        with pytest.raises(exc):
+            unet_amd.DAU(**bad)
+
+
+@pytest.mark.parametrize("label,kw", [("plain", {}), ("dsb", dict(DSB=True))])
+def test_dau_helper_wave_to_wave(device, label, kw):
+    """DAU_helper end to end against the reference's golden output and the oracle; the direction and microphone
+    positions are handed over as host tensors (no device wait for the path-length differences)."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.DAU_helper(**kw).eval()
+    unet_amd.seeded_fill_(ref, seed=86)
+    dev = unet_amd.DAU_helper(**kw)
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    wav = normal("dau_helper/x", (2, 4, 4000), seed=86) * 0.1
+    angle = uniform("dau_helper/angle", (2,), 0.0, 360.0, seed=86)
+    mic = uniform("dau_helper/mic", (2, 4, 3), -0.05, 0.05, seed=86)
+    with torch.no_grad():
+        want = ref(wav, angle, mic)
+        got = dev(wav.to(device), angle, mic)
+        got_dev_args = dev(wav.to(device), angle.to(device), mic.to(device))
+    golden = torch.from_numpy(load_golden("dau_helper_eval")[label])
+    assert_close(got, golden, what="DAU_helper HIP vs golden")
+    assert_close(got, want, what="DAU_helper HIP vs oracle")
+    assert torch.equal(got, got_dev_args)
+
+
 @pytest.mark.parametrize("label,kw", [("plain", {}), ("dsb", dict(DSB=True))])
 def test_udss_helper_wave_to_wave(device, label, kw):
     """UDSS_helper end to end (device STFT, complex features, UDSS, mask, inverse STFT) against the golden output of

@@ -171,6 +171,40 @@ def test_udss_helper_matches_golden():
         assert_close(y, torch.from_numpy(gold[label]), tol=CPU_TOL, what="UDSS_helper " + label)
 
 
+def test_dau_matches_golden():
+    """DTU.py's DAU and DAU_helper restatements against the reference's outputs (tests/golden/make_golden.py)."""
+    gold = load_golden("dau_eval")
+    for label, kw in (("crm", {}), ("mea", dict(type_masking="MEA"))):
+        net = oracle.DAU(**kw).eval()
+        seeded_fill_(net, seed=81)
+        sf = normal("dau/sf", (2, 4, 257, 16, 2), seed=81)
+        SV = normal("dau/SV", (2, 4, 514), seed=81)
+        ang = uniform("dau/theta", (2,), 0.0, 2 * np.pi, seed=81)
+        theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+        with torch.no_grad():
+            y = net(sf, SV, theta)
+        assert y.dtype == torch.complex64 and tuple(y.shape) == (2, 257, 16)
+        assert_close(torch.view_as_real(y), torch.from_numpy(gold[label]), tol=CPU_TOL, what="DAU " + label)
+    gold = load_golden("dau_helper_eval")
+    for label, kw in (("plain", {}), ("dsb", dict(DSB=True))):
+        net = oracle.DAU_helper(**kw).eval()
+        seeded_fill_(net, seed=86)
+        wav = normal("dau_helper/x", (2, 4, 4000), seed=86) * 0.1
+        angle = uniform("dau_helper/angle", (2,), 0.0, 360.0, seed=86)
+        mic = uniform("dau_helper/mic", (2, 4, 3), -0.05, 0.05, seed=86)
+        with torch.no_grad():
+            y = net(wav, angle, mic)
+        assert_close(y, torch.from_numpy(gold[label]), tol=CPU_TOL, what="DAU_helper " + label)
+    # the reference's constructor refuses these (Exception / TypeError from nn.PReLU(inplace=True))
+    for bad, exc in ((dict(bottleneck="TGRU"), Exception), (dict(activation="PReLU"), TypeError),
+                     (dict(type_masking="CM"), Exception)):
+        try:
+            oracle.DAU(**bad)
+            raise AssertionError("DAU({}) should fail like the reference".format(bad))
+        except exc:
+            pass
+
+
 def test_dsunet_matches_golden():
     net = oracle.DSUNet(oracle.dsunet_architecture(45, 8)).eval()
     seeded_fill_(net, seed=41)

@@ -486,6 +486,8 @@ class UDSS(nn.Module):
     """``complex=True``, ``type_encoder="Complex"``, bottleneck "None" / "TGRU" / "FTGRU" / "cRNN", masks "CRM" / "CM" / "CMEA".  As in the
     reference the default ``type_norm`` ("BatcNorm2d", sic) fails at construction; pass "BatchNorm2d"."""
 
+    _announce = "UDSS"          # the name printed with the model complexity (the reference prints at construction)
+
     def __init__(self, input_channels=4, n_fft=512, complex=True, model_complexity=45, bottleneck="None",
                  padding_mode="zeros", type_encoder="Complex", type_masking="CRM", activation="LeakyReLU",
                  dropout=0.0, type_norm="BatcNorm2d"):
@@ -496,7 +498,7 @@ class UDSS(nn.Module):
         self.complex = complex
         self.n_channel = input_channels
         model_complexity = int(model_complexity // 1.414)
-        print("UDSS::complexity {}".format(model_complexity))
+        print("{}::complexity {}".format(self._announce, model_complexity))
         self.set_size(model_complexity=model_complexity, input_channels=input_channels, model_depth=20)
         L = self.model_length = 10
         self.dropout = dropout
@@ -651,9 +653,9 @@ class UDSS_helper(_helper_base()):
         feat_src = X
         if self.corr:
             feat_src = torch.cat([X[:, :1], X[:, :1] * X[:, 1:]], dim=1)
-        SV = self.steering_vector(angle, mic_pos)
+        SV = self.steering_vector(angle, mic_pos, x.device)
         SV = torch.cat((SV.real, SV.imag), -1)
-        theta = self.anlge_pre(angle)
+        theta = self.anlge_pre(angle.to(x.device, non_blocking=True))
         feat = feat_src
         if self.DSB:
             feat = torch.cat((feat_src, self.delay_n_sum(feat_src, angle, mic_pos)[:, None]), dim=1)
@@ -662,5 +664,8 @@ class UDSS_helper(_helper_base()):
             self.net.bf16_matrix = True
             spectral_feature = spectral_feature.to(torch.bfloat16)
         mask = self.net(spectral_feature, SV, theta)
-        Y = self.net.masking(feat_src[:, 0], mask)
+        Y = self._apply_mask(feat_src[:, 0], mask)
         return self._stft.istft(Y.contiguous(), L)
+
+    def _apply_mask(self, X0, mask):
+        return self.net.masking(X0, mask)

@@ -13,9 +13,10 @@ from .cRFUNet import UNet20, UNet10
 from .DSUNet import DSUNet, DSUNet_helper
 from .ResUNet import ResUNet, ResUNetOnFreq, ResUNetOnFreq2
 from .UDSS import UDSS, UDSS_helper
+from .DTU import DAU, DAU_helper
 from .tables import dsunet_architecture
 from .seeding import seeded_fill_
 
-__all__ = ["Encoder", "Decoder", "ResBlock", "UNet", "UNet20", "UNet10", "DSUNet", "DSUNet_helper", "ResUNet", "ResUNetOnFreq", "ResUNetOnFreq2", "UDSS", "UDSS_helper",
+__all__ = ["Encoder", "Decoder", "ResBlock", "UNet", "UNet20", "UNet10", "DSUNet", "DSUNet_helper", "ResUNet", "ResUNetOnFreq", "ResUNetOnFreq2", "UDSS", "UDSS_helper", "DAU", "DAU_helper",
            "default_unet_blocks",
            "dsunet_architecture", "seeded_fill_"]
