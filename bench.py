@@ -184,6 +184,13 @@ def run_train(args, ranks):
     target = torch.cat([torch.rand((1, 1, F_BINS, T_PADDED), generator=torch.Generator().manual_seed(99 + i))
                         for i in range(lo, hi)]).to(dev)
     verbose = os.environ.get("UNETMI_BENCH_VERBOSE") == "1"
+    exchange = "torch.distributed ({})".format(ranks.backend)
+    if args.comm == "unetmi" and ranks.backend != "gloo":
+        # the library's own RCCL communicator (unetmi_comm_init / unetmi_allreduce_f32); its id travels through
+        # the torch.distributed group that the launcher set up
+        from unet_amd import comm
+        comm.init_from_torch_distributed(dev)
+        exchange = "unetmi_allreduce_f32 (RCCL, {} ranks)".format(comm.world())
     for i in range(args.warmup):
         loss = train_step(net, opt, x, target)
         if verbose:
@@ -215,7 +222,7 @@ def run_train(args, ranks):
                    "per_gpu_batch": hi - lo, "global_batch": total,
                    "gflop_per_utterance": 3 * 64.34, "parallelism": "data-parallel x{}".format(world),
                    "final_loss": float(loss.item())},
-        "ranks_seen": seen, "backend": ranks.backend,
+        "ranks_seen": seen, "backend": ranks.backend, "gradient_exchange": exchange,
         "per_rank_ms": [1e3 * t / args.steps for t in per_rank],
         "roofline": {"bound": "mfma", "kernel": "whole step (conv fwd + dgrad + wgrad)", "achieved": achieved,
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -235,6 +242,9 @@ def main():
     ap.add_argument("--layers", action="store_true", help="per-layer times of the last step on stderr")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward: the headline metric (default); train: the data-parallel training step")
+    ap.add_argument("--comm", choices=["torch", "unetmi"], default="torch",
+                    help="train mode: gradient all-reduce through torch.distributed (default) or through the "
+                         "library's own RCCL entry points")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed global batch sharded over the ranks (strong scaling); default 64 per GPU (8 for train)")
     ap.add_argument("--plumbing-only", action="store_true",

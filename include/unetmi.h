@@ -328,6 +328,26 @@ int unetmi_adam_step(size_t n, float* param, const float* grad, float* exp_avg, 
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
                      void* stream);
 
+/* The training step's gradient exchange: an in-place fp32 SUM all-reduce over RCCL, one process per GPU, one
+ * communicator per process.  The reference has no distributed code (its modules are trained by user scripts);
+ * this replaces what such a script would do with torch.distributed.all_reduce on the gradients of the modules
+ * of UNet.py:7-113.  The RCCL library is located when the communicator is created (the copy already loaded in
+ * the process, else the system's); without one these calls return UNETMI_E_UNSUPPORTED and every other entry
+ * point still works.
+ *   unetmi_comm_unique_id  rank 0 fills UNETMI_COMM_ID_BYTES opaque bytes and hands them to the other ranks
+ *                          through the job's own channel (TCP store, file, MPI)
+ *   unetmi_comm_init       every rank, with the GPU it owns current; collective (returns when all have joined)
+ *   unetmi_allreduce_f32   enqueues buf[i] = sum over ranks of buf[i] on `stream`; divide by the world size in
+ *                          unetmi_adam_step's grad_scale
+ *   unetmi_comm_world      the communicator's size, 0 without one
+ *   unetmi_comm_destroy    releases it (a later unetmi_comm_init may create another) */
+#define UNETMI_COMM_ID_BYTES 128
+int unetmi_comm_unique_id(void* id128);
+int unetmi_comm_init(int rank, int world, const void* id128);
+int unetmi_comm_world(void);
+int unetmi_allreduce_f32(float* buf, size_t n, void* stream);
+int unetmi_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -221,3 +221,35 @@ def test_eval_after_training_uses_updated_weights(device):
         want = ref(x.cpu())
     assert not torch.equal(y0, y1)
     assert_close(y1, want, what="eval forward after two optimizer steps")
+
+
+def test_library_communicator_single_rank(device):
+    """unetmi_comm_* / unetmi_allreduce_f32 (RCCL behind the C ABI) with a one-rank communicator: the sum
+    all-reduce leaves the bucket as it was, FlatBucket.all_reduce takes this path once a communicator exists,
+    and the entry points refuse misuse.  More than one rank needs more than one GPU (RCCL refuses two ranks on
+    one device); the multi-rank plumbing around it is covered by the gloo tests on the host."""
+    import unet_amd
+    from unet_amd import _lib, comm
+    from unet_amd.train import FlatBucket
+    assert comm.world() == 0
+    t = torch.arange(1000, dtype=torch.float32, device=device) * 0.5
+    with pytest.raises(_lib.UnetmiError):
+        comm.all_reduce_sum_(t.clone())                 # no communicator yet
+    assert comm.init_from_torch_distributed(device) == 1
+    try:
+        assert comm.world() == 1
+        with pytest.raises(_lib.UnetmiError):
+            comm.init(0, 1, comm.unique_id(), device)   # one communicator per process
+        got = comm.all_reduce_sum_(t.clone())
+        torch.cuda.synchronize()
+        assert torch.equal(got, t)
+        p = torch.nn.Parameter(torch.ones(257, device=device))
+        bucket = FlatBucket([p])
+        bucket.grad.copy_(torch.linspace(-1, 1, 257, device=device))
+        before = bucket.grad.clone()
+        assert bucket.all_reduce() == 1
+        torch.cuda.synchronize()
+        assert torch.equal(bucket.grad, before)
+    finally:
+        comm.destroy()
+    assert comm.world() == 0

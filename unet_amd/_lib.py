@@ -45,6 +45,11 @@ EXPORTED_SYMBOLS = (
     "unetmi_conv2d_b16_fwd",
     "unetmi_blocked_from_nchw",
     "unetmi_nchw_from_blocked",
+    "unetmi_comm_unique_id",
+    "unetmi_comm_init",
+    "unetmi_comm_world",
+    "unetmi_allreduce_f32",
+    "unetmi_comm_destroy",
 )
 
 
@@ -123,6 +128,14 @@ def _load():
     lib.unetmi_blocked_from_nchw.restype = ctypes.c_int
     lib.unetmi_nchw_from_blocked.argtypes = [ci] * 3 + [fp, fp, ci, vp]
     lib.unetmi_nchw_from_blocked.restype = ctypes.c_int
+    lib.unetmi_comm_unique_id.argtypes = [vp]
+    lib.unetmi_comm_init.argtypes = [ci, ci, vp]
+    lib.unetmi_comm_world.argtypes = []
+    lib.unetmi_allreduce_f32.argtypes = [fp, sz, vp]
+    lib.unetmi_comm_destroy.argtypes = []
+    for f in (lib.unetmi_comm_unique_id, lib.unetmi_comm_init, lib.unetmi_comm_world, lib.unetmi_allreduce_f32,
+              lib.unetmi_comm_destroy):
+        f.restype = ctypes.c_int
     for f in (lib.unetmi_bn_train_stats, lib.unetmi_bn_act_fwd, lib.unetmi_bn_act_bwd, lib.unetmi_conv2d_wgrad,
               lib.unetmi_adam_step):
         f.restype = ctypes.c_int

@@ -259,6 +259,11 @@ class FlatBucket:
         """Sum the gradient bucket over the data-parallel group (RCCL on GPUs); returns the group
         size, by which the caller divides (FlatAdam.step folds the division into the update)."""
         import torch.distributed as dist
+        from . import comm
+        if self.grad.is_cuda and group is None and comm.world() > 0:
+            # the library's own communicator (unetmi_comm_init): one ncclAllReduce on the current stream
+            comm.all_reduce_sum_(self.grad)
+            return comm.world()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             if dist.get_backend(group) == "gloo" and self.grad.is_cuda and os.environ.get("UNETMI_GLOO_DEVICE_TENSORS") != "1":
                 # gloo stages device tensors through the host on its own streams; do the staging here,
