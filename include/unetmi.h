@@ -328,6 +328,12 @@ int unetmi_adam_step(size_t n, float* param, const float* grad, float* exp_avg, 
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
                      void* stream);
 
+/* dst[i] = map[i] >= 0 ? src[map[i]] : 0 for i < n.  With the map of a layer (the element numbers that
+ * unetmi_conv2d_pack_weights puts at each position of the packed image, -1 for padding; found once per layer
+ * shape by packing a numbered tensor on the host) this re-packs a weight tensor on the device after every
+ * optimizer step.  No counterpart in the reference, whose convolutions read nn.Conv2d.weight directly. */
+int unetmi_gather_f32(size_t n, const float* src, const int* map, float* dst, void* stream);
+
 /* The training step's gradient exchange: an in-place fp32 SUM all-reduce over RCCL, one process per GPU, one
  * communicator per process.  The reference has no distributed code (its modules are trained by user scripts);
  * this replaces what such a script would do with torch.distributed.all_reduce on the gradients of the modules

@@ -253,3 +253,74 @@ def test_library_communicator_single_rank(device):
     finally:
         comm.destroy()
     assert comm.world() == 0
+
+
+def test_full_width_train_step_matches_oracle(device):
+    """One training step of the full-width UNet (f_dim 32: the benchmark's channel counts, the 64- and 128-channel
+    kernels and their weight-gradient instantiations) at B=2, T=45: loss, every gradient and the BatchNorm running
+    statistics against the oracle.
+
+    LeakyReLU's derivative jumps at zero.  The device's pre-activations differ from the CPU's in the last bits, so
+    among 1.5 million of them per layer about one lands on the other side of zero, and that single element moves a
+    per-channel gradient sum by up to 1e-2 of its value -- not an arithmetic error of the backward kernels.  The
+    gradients are therefore compared with float64 autograd of the oracle run WITH THE DEVICE'S ACTIVATION PATTERN
+    (the sign of every block output, captured from the device forward), to 1e-4 of each tensor's largest entry;
+    the number of pre-activations whose sign differs from the oracle's own is reported and bounded."""
+    import torch.nn as nn
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    from unet_amd.train import FlatAdam
+    ref = oracle.UNet(*oracle.default_unet(c_in=2, c_last=1, f_dim=32))
+    unet_amd.seeded_fill_(ref, seed=31)
+    dev = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=32))
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    xb = normal("unet_full/xb", (2, 2, 257, 45), seed=32)
+    target = uniform("unet_full/target", (2, 1, 257, 45), 0.0, 1.0, seed=32)
+    ref64 = copy.deepcopy(ref).double().train()
+    ref.train()
+    loss_ref = torch.mean((ref(xb) - target) ** 2)
+
+    dev.to(device).train()
+    masks = {}
+    handles = [m.register_forward_hook(lambda mod, i, o, n=name: masks.__setitem__(n, (o.detach() >= 0).cpu()))
+               for name, m in dev.named_modules() if isinstance(m, (unet_amd.Encoder, unet_amd.Decoder))]
+    opt = FlatAdam(dev.parameters(), lr=1e-3)
+    opt.zero_grad()
+    loss = torch.mean((dev(xb.to(device)) - target.to(device)) ** 2)
+    loss.backward()
+    for h in handles:
+        h.remove()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    assert len(masks) == 20
+
+    flips = [0, 0]
+
+    def device_pattern(name):
+        def hook(mod, inp, out):
+            pre = inp[0]
+            flips[0] += int(((pre >= 0) != masks[name]).sum())
+            flips[1] += pre.numel()
+            return pre * torch.where(masks[name], 1.0, mod.negative_slope).to(pre.dtype)
+        return hook
+    for name, m in ref64.named_modules():
+        if isinstance(getattr(m, "acti", None), nn.LeakyReLU):
+            m.acti.inplace = False          # the hook needs the pre-activation as it was
+            m.acti.register_forward_hook(device_pattern(name))
+    torch.mean((ref64(xb.double()) - target.double()) ** 2).backward()
+    assert flips[1] > 1e6 and flips[0] <= 1e-5 * flips[1], flips
+    exact = {k: p.grad for k, p in ref64.named_parameters()}
+    gmax = max(g.abs().max().item() for g in exact.values())
+    worst = 0.0
+    for k, p in dev.named_parameters():
+        g = p.grad.detach().cpu().double()
+        scale = max(exact[k].abs().max().item(), 1e-3 * gmax)
+        err = (g - exact[k]).abs().max().item()
+        worst = max(worst, err / scale)
+        assert err <= 1e-4 * scale, "grad {}: err {:.3e} of scale {:.3e}".format(k, err, scale)
+    after_ref = ref.state_dict()
+    for k, v in dev.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert_close(v.detach().cpu(), after_ref[k], tol=1e-5, what="running statistic " + k)
+    print("full-width train step: loss {:.6f}; {} of {} pre-activations on the other side of zero than the oracle's; "
+          "worst gradient error {:.2e} of its tensor's scale".format(loss.item(), flips[0], flips[1], worst))

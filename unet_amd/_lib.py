@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "unetmi_conv2d_b16_fwd",
     "unetmi_blocked_from_nchw",
     "unetmi_nchw_from_blocked",
+    "unetmi_gather_f32",
     "unetmi_comm_unique_id",
     "unetmi_comm_init",
     "unetmi_comm_world",
@@ -128,6 +129,8 @@ def _load():
     lib.unetmi_blocked_from_nchw.restype = ctypes.c_int
     lib.unetmi_nchw_from_blocked.argtypes = [ci] * 3 + [fp, fp, ci, vp]
     lib.unetmi_nchw_from_blocked.restype = ctypes.c_int
+    lib.unetmi_gather_f32.argtypes = [sz, fp, fp, fp, vp]
+    lib.unetmi_gather_f32.restype = ctypes.c_int
     lib.unetmi_comm_unique_id.argtypes = [vp]
     lib.unetmi_comm_init.argtypes = [ci, ci, vp]
     lib.unetmi_comm_world.argtypes = []

@@ -285,6 +285,16 @@ static int launched(const char* what) {
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
 }
 
+// packed[i] = map[i] >= 0 ? weight[map[i]] : 0 -- re-packs a weight tensor into a kernel's image on the device
+// (the host-side pack is a permutation with zero padding, so it is one gather once the map is known).
+__global__ __launch_bounds__(256) void gather_kernel(size_t n, const float* __restrict__ src,
+                                                     const int* __restrict__ map, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int m = map[i];
+    dst[i] = m >= 0 ? src[m] : 0.f;
+}
+
 }  // namespace unetmi
 
 using namespace unetmi;
@@ -390,6 +400,15 @@ int unetmi_adam_step(size_t n, float* param, const float* grad, float* exp_avg, 
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
                        param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, sqrt_bc2);
     return launched("adam_step");
+}
+
+int unetmi_gather_f32(size_t n, const float* src, const int* map, float* dst, void* stream) {
+    if (n == 0) return UNETMI_OK;
+    if (!src || !map || !dst) return api_fail(UNETMI_E_BAD_ARG, "gather_f32: null pointer");
+    if ((n + 255) / 256 > 0x7fffffffull) return api_fail(UNETMI_E_UNSUPPORTED, "gather_f32: too many elements");
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
+                       src, map, dst);
+    return launched("gather_f32");
 }
 
 }  // extern "C"

@@ -357,6 +357,7 @@ _LIBRARY.define("bn_act_bwd(Tensor dy, Tensor z, Tensor mean, Tensor invstd, Ten
 _LIBRARY.define("conv2d_wgrad(Tensor in0, Tensor? in1, Tensor dout, int[] geom, int[] flags) -> Tensor")
 _LIBRARY.define("adam_step(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, "
                 "float beta2, float eps, float weight_decay, float grad_scale, int step) -> ()")
+_LIBRARY.define("gather_f32(Tensor src, Tensor map) -> Tensor")
 _LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool xcd) -> Tensor")
 _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
 _LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
@@ -467,6 +468,16 @@ def _adam_step_cuda(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, wei
         check(_lib.lib.unetmi_adam_step(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), lr,
                                         beta1, beta2, eps, weight_decay, grad_scale, step, _stream(param)),
               "unetmi_adam_step")
+
+
+def _gather_f32_cuda(src, map):
+    """out[i] = src.flatten()[map[i]], 0 where map[i] < 0 (int32 map): the device-side weight re-pack."""
+    _dev(src, "src", "gather_f32")
+    _dev(map, "map", "gather_f32", torch.int32)
+    out = torch.empty(map.numel(), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        check(_lib.lib.unetmi_gather_f32(map.numel(), _ptr(src), _ptr(map), _ptr(out), _stream(src)), "unetmi_gather_f32")
+    return out
 
 
 _lstm_scratch = {}
@@ -588,7 +599,7 @@ def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param
 
 for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_act_fwd", _bn_act_fwd_cuda),
                    ("bn_act_bwd", _bn_act_bwd_cuda), ("conv2d_wgrad", _conv2d_wgrad_cuda),
-                   ("adam_step", _adam_step_cuda), ("lstm_recurrence", _lstm_recurrence_cuda),
+                   ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda),
                    ("blocked_from_nchw", _blocked_from_nchw_cuda), ("nchw_from_blocked", _nchw_from_blocked_cuda),
                    ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda)):
     _LIBRARY.impl(_name, _fn, "CUDA")
@@ -619,6 +630,11 @@ def _(in0, in1, dout, geom, flags):
 @torch.library.register_fake("unetmi::adam_step")
 def _(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
     return None
+
+
+@torch.library.register_fake("unetmi::gather_f32")
+def _(src, map):
+    return src.new_empty((map.numel(),))
 
 
 @torch.library.register_fake("unetmi::lstm_recurrence")
@@ -653,6 +669,7 @@ bn_act_fwd = torch.ops.unetmi.bn_act_fwd
 bn_act_bwd = torch.ops.unetmi.bn_act_bwd
 conv2d_wgrad = torch.ops.unetmi.conv2d_wgrad
 adam_step = torch.ops.unetmi.adam_step
+gather_f32 = torch.ops.unetmi.gather_f32
 lstm_recurrence = torch.ops.unetmi.lstm_recurrence
 blocked_from_nchw = torch.ops.unetmi.blocked_from_nchw
 nchw_from_blocked = torch.ops.unetmi.nchw_from_blocked

@@ -69,7 +69,8 @@ _pack_index_cache = {}
 
 
 def device_pack_index(cin, geom, transposed, device, c1=0):
-    """int64 gather map of unetmi_conv2d_pack_weights: packed = cat(weight.flatten(), [0])[map].
+    """int32 gather map of unetmi_conv2d_pack_weights for unetmi_gather_f32: packed[i] = weight.flatten()[map[i]],
+    0 where map[i] is -1.
     The pack is a permutation with zero padding, so the map is found once per layer shape by
     packing the element numbers on the host."""
     key = (cin, c1, tuple(geom), int(transposed), str(device))
@@ -82,11 +83,21 @@ def device_pack_index(cin, geom, transposed, device, c1=0):
             raise ValueError("weight tensor too large for the float-coded index map")
         numbered = torch.arange(1, numel + 1, dtype=torch.float32).reshape(shape)
         packed = pack_conv_weights(numbered, cin - c1, c1, geom, [int(transposed), _lib.IN_SINGLE, _lib.ACT_NONE, 0])
-        idx = packed.round().long() - 1
-        idx[idx < 0] = numel                       # -> the appended zero
-        idx = idx.to(device)
+        idx = (packed.round().long() - 1).to(torch.int32).to(device)         # -1 = padding
         _pack_index_cache[key] = idx
     return idx
+
+
+_const_cache = {}
+
+
+def _constant(value, n, device):
+    """A cached fp32 vector of n copies of value (never written: epilogue identity parameters)."""
+    key = (float(value), int(n), str(device))
+    t = _const_cache.get(key)
+    if t is None:
+        t = _const_cache[key] = torch.full((n,), float(value), dtype=torch.float32, device=device)
+    return t
 
 
 def pack_on_device(weight, geom, transposed, c1=0):
@@ -94,16 +105,14 @@ def pack_on_device(weight, geom, transposed, c1=0):
     the channels per source, so the image depends on the split)."""
     cin = weight.shape[0] if transposed else weight.shape[1]
     idx = device_pack_index(cin, geom, transposed, weight.device, c1)
-    flat = torch.cat([weight.detach().reshape(-1), weight.new_zeros(1)])
-    return flat[idx]
+    return _ops.gather_f32(weight.detach().contiguous(), idx)        # one launch; padding positions are -1 in the map
 
 
 def _plain_conv(x, x2, weight, bias, geom, transposed):
     """conv / transposed conv + bias, nothing else."""
     K = geom[0]
     wpacked = pack_on_device(weight, geom, transposed, x2.shape[1] if x2 is not None else 0)
-    ones = torch.ones(K, dtype=torch.float32, device=x.device)
-    zeros = torch.zeros_like(ones)
+    ones, zeros = _constant(1.0, K, x.device), _constant(0.0, K, x.device)
     b = bias.detach() if bias is not None else zeros
     mode = _lib.IN_SINGLE if x2 is None else _lib.IN_CONCAT
     flags = [int(transposed), mode, _lib.ACT_NONE, 0]
@@ -156,10 +165,9 @@ class ConvNormAct(torch.autograd.Function):
             mean = bn.running_mean.detach()
             invstd = torch.rsqrt(bn.running_var.detach() + bn.eps)
         else:
-            mean = torch.zeros(K, dtype=torch.float32, device=dev)
-            invstd = torch.ones_like(mean)
-        g = gamma.detach() if gamma is not None else torch.ones(K, dtype=torch.float32, device=dev)
-        b = beta.detach() if beta is not None else torch.zeros(K, dtype=torch.float32, device=dev)
+            mean, invstd = _constant(0.0, K, dev), _constant(1.0, K, dev)
+        g = gamma.detach() if gamma is not None else _constant(1.0, K, dev)
+        b = beta.detach() if beta is not None else _constant(0.0, K, dev)
         y = bn_act_fwd(z, mean, invstd, g, b, cfg["act"], cfg["act_param"])
         ctx.cfg = cfg
         ctx.in_hw = tuple(x.shape[2:])
