@@ -461,6 +461,8 @@ def assert_bf16_close(got, want, what):
         got, want = torch.view_as_real(got), torch.view_as_real(want)
     got, want = got.float(), want.float()
     l2 = ((got - want).norm() / want.norm()).item()
+    mx = ((got - want).abs().max() / want.abs().max()).item()
+    print("{}: relative L2 {:.3e}, max-norm {:.3e}".format(what, l2, mx))          # both figures, every bf16 test
     assert l2 <= BF16_L2_TOL, "{}: relative L2 error {:.3e} > {:.1e}".format(what, l2, BF16_L2_TOL)
     assert_close(got, want, tol=BF16_MAX_TOL, what=what)
 
@@ -480,6 +482,11 @@ def test_resunet_bf16_storage(device):
     xb = x.to(torch.bfloat16)
     with torch.no_grad():
         want = ref(xb.float())                      # same (bf16-representable) input values
+        got = dev(xb.to(device))                    # default: bfloat16 at the boundary, fp32 tensors inside
+        assert got.dtype == torch.bfloat16
+        assert_bf16_close(got, want, "ResUNet bf16 in/out, fp32 inside")
+        assert_close(got.float(), want, tol=1e-2, what="ResUNet bf16 in/out: the fp32 tests' max-norm figure at 1e-2")
+        dev.bf16_storage = True                     # every intermediate tensor bfloat16
         got = dev(xb.to(device))
     assert got.dtype == torch.bfloat16
     assert_bf16_close(got, want, "ResUNet bf16 storage")
@@ -508,9 +515,6 @@ def test_dsunet_bf16(device):
             got = dev(sf.to(device), SV.to(device), theta.to(device))
             assert got.dtype == torch.complex64
             what = "DSUNet bf16 " + ("operands, blocked layout" if matrix else "storage, NCHW")
-            g, w = torch.view_as_real(got.cpu()), torch.view_as_real(want)
-            print("{}: relative L2 {:.3e}, max-norm {:.3e}".format(
-                what, ((g - w).norm() / w.norm()).item(), ((g - w).abs().max() / w.abs().max()).item()))
             assert_bf16_close(got, want, what)
     assert dev._blocked, "the blocked bf16 path was not taken"
 

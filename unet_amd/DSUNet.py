@@ -328,6 +328,7 @@ class DSUNet(nn.Module):
         # (unet_amd/blocked.py) when every layer is one that kernel serves; False keeps the NCHW
         # bfloat16-storage kernels (fp32 products)
         self.bf16_matrix = True
+        self.bf16_full_res_halves = 2
 
     def _blocked_layers(self):
         """BlockedConv per encoder / decoder / head, or False when a layer is outside that kernel."""
@@ -343,11 +344,17 @@ class DSUNet(nn.Module):
                     getattr(conv, "padding_mode", "zeros") == "zeros"
             built = False
             if ok:
-                built = dict(enc=[BlockedConv(m.conv, m.bn, m.relu) for m in self.encoders],
+                # The first encoder and the head are bound by their activation traffic, not by the matrix cores:
+                # there a weight goes in as bfloat16 plus its rounding remainder (two MFMAs per product, fp32-weight
+                # accuracy).  Measured at batch 32: 6.41 -> 6.52 ms, max-norm error 9.9e-3 -> 8.4e-3; the last
+                # decoder as well would give 7.8e-3 for 7.17 ms.
+                hv = self.bf16_full_res_halves
+                built = dict(enc=[BlockedConv(m.conv, m.bn, m.relu, halves=hv if i < 1 else 1)
+                                  for i, m in enumerate(self.encoders)],
                              dec=[BlockedConv(m.transconv, m.bn, m.relu) for m in self.decoders],
                              # the head writes its two channels as fp32 NCHW; the squash runs on that small
                              # tensor (inlined per accumulator, the transcendental epilogue doubles the launch)
-                             head=BlockedConv(self.linear, None, None, nchw_out=True))
+                             head=BlockedConv(self.linear, None, None, halves=hv, nchw_out=True))
             object.__setattr__(self, "_blocked", built)
         return self._blocked
 

@@ -119,10 +119,21 @@ class ResUNet(nn.Module):
         ln = branch[1]
         layernorm_f(fused(x), ln.weight.float(), ln.bias.float(), ln.eps, out, c_off)
 
+    # What a bfloat16 input selects.  False (default): bfloat16 at the boundary only -- the input is widened once,
+    # every tensor between kernels is fp32 and the output is rounded to bfloat16.  Measured on this network, storing
+    # the intermediate tensors as bfloat16 makes the forward slower (36.6 against 30.7 ms at batch 32: its time is
+    # in kernels bound by instruction issue, not by HBM bytes, and rows of 501 two-byte elements are not 4-byte
+    # aligned, which the 16-byte LDS-DMA groups of the residual-block kernel need) and less accurate (max-norm
+    # error 1.0e-2 .. 1.4e-2 against 2e-3).  True: bfloat16 storage of every intermediate tensor (half the
+    # activation memory), fp32 arithmetic.
+    bf16_storage = False
+
     def forward(self, input):
         require_device_tensor(input, "ResUNet")
         if self.training:
             raise NotImplementedError("ResUNet: train-mode forward is not available in this build; call .eval()")
+        if input.dtype == torch.bfloat16 and not self.bf16_storage:
+            return self.forward(input.float()).to(torch.bfloat16)
         B, _, F, T = input.shape
         x = torch.empty((B, 64, F, T), dtype=input.dtype, device=input.device)
         self._input_branch(self.layer_data, "_in_data", input[:, :-2].contiguous(), x, 0)
