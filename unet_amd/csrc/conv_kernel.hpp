@@ -300,10 +300,81 @@ __device__ __forceinline__ void conv_epilogue_body(const f32x16 (&acc)[NG][TPG],
     }
 }
 
+// The same epilogue for kernels with ONE column phase (NG == 1), without branches or 64-bit address arithmetic:
+// the output (and the residual) of sample n is addressed through a buffer descriptor over that sample, the
+// lane-dependent part of the address (column, and which half of the channel group the lane holds) is ONE byte
+// offset per lane for all its results, and the part that changes from result to result (channel, row) is
+// wave-uniform and travels as the instruction's scalar offset.  A lane whose column or channel is outside the
+// tensor carries an offset beyond the descriptor's range, so its loads return zero and its stores are dropped.
+// All residual values of a row group are requested before the first one is used.
+template <int TPG, bool BF16, int ACT>
+__device__ __forceinline__ void conv_epilogue_body_ng1(const f32x16 (&acc)[1][TPG], const ConvArgs& p,
+                                                       const float* s_par, int n, int cb, int a, int i0, int j0,
+                                                       int wm, int wn, int half, int j) {
+    constexpr int EB = BF16 ? 2 : 4;
+    constexpr int kDrop = (int)0x80000000;
+    const int col_base = wn * 32 + 4 * half;
+    const int OHW = p.OH * p.OW;
+    const int sample_bytes = p.K * OHW * EB;                   // < 2^31: checked when the layer is planned
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        static_cast<char*>(static_cast<void*>(p.out)) + (size_t)n * sample_bytes, 0, sample_bytes, 0x00020000);
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(static_cast<const void*>(p.residual ? p.residual : p.out))) +
+            (size_t)n * sample_bytes, 0, p.residual ? sample_bytes : 0, 0x00020000);
+    const int jj = j0 + j;
+    const int co0 = cb * p.NB + col_base;                      // the lane's first channel
+    // byte offset of (channel 4*half of this wave's 32, row 0, this lane's column)
+    const int lane_off = jj < p.w_nout[0] ? (4 * half * OHW + jj * p.w_nphase) * EB : kDrop;
+    const int chan0 = cb * p.NB + wn * 32;                     // uniform: first channel of this wave's 32
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+        const int i = i0 + wm * TPG + t;
+        if (i >= p.h_nout[a]) continue;                        // wave-uniform
+        const int oh = i * p.h_nphase + a;
+        const int row_off = (chan0 * p.OH + oh) * p.OW * EB;   // uniform byte offset of (channel chan0, row oh)
+        int voff[16];
+        float res[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2);              // channel of register r, relative to the lane's first
+            voff[r] = (co0 + c < p.K) ? lane_off : kDrop;
+            res[r] = 0.f;
+        }
+        if (p.residual) {                                      // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                res[r] = buf_ld_act<BF16>(rs_res, voff[r], row_off + ((r & 3) + 8 * (r >> 2)) * OHW * EB);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            const int cl = col_base + c;
+            float v = acc[0][t][r] + s_par[cl];
+            const float sc = s_par[p.NB + cl], sf = s_par[2 * p.NB + cl], sl = s_par[3 * p.NB + cl];
+            if (p.act_first) v = apply_act<ACT>(v, sl) * sc + sf;
+            else             v = apply_act<ACT>(v * sc + sf, sl);
+            v = v * s_par[4 * p.NB + cl] + res[r];
+            if (!ABLATE(4) || v == 123.456f) buf_st_act<BF16>(v, rs_out, voff[r], row_off + c * OHW * EB);
+        }
+    }
+}
+
 template <int NG, int TPG, bool BF16 = false>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NG][TPG], const ConvArgs& p,
                                               const float* s_par, int n, int cb, int a, int i0, int j0,
                                               int wm, int wn, int half, int j) {
+    if constexpr (NG == 1) {
+        switch (p.act) {
+#define UNETMI_EPI1(A_) \
+        case A_: conv_epilogue_body_ng1<TPG, BF16, A_>(acc, p, s_par, n, cb, a, i0, j0, wm, wn, half, j); return;
+            UNETMI_EPI1(UNETMI_ACT_LEAKY) UNETMI_EPI1(UNETMI_ACT_RELU) UNETMI_EPI1(UNETMI_ACT_SILU)
+            UNETMI_EPI1(UNETMI_ACT_SOFTPLUS) UNETMI_EPI1(UNETMI_ACT_SIGMOID) UNETMI_EPI1(UNETMI_ACT_TANH)
+            UNETMI_EPI1(UNETMI_ACT_GELU)
+#undef UNETMI_EPI1
+            default: conv_epilogue_body_ng1<TPG, BF16, UNETMI_ACT_NONE>(acc, p, s_par, n, cb, a, i0, j0, wm, wn, half, j);
+        }
+        return;
+    }
     switch (p.act) {
 #define UNETMI_EPI(A_) \
     case A_: conv_epilogue_body<NG, TPG, BF16, A_>(acc, p, s_par, n, cb, a, i0, j0, wm, wn, half, j); break;

@@ -156,6 +156,9 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     if ((long long)d.H * d.W * 4 * std::max(std::max(d.C0, d.C1), 34) >= (1ll << 30)) {
         *err = "image too large for 32-bit buffer offsets"; return false;
     }
+    if ((long long)d.K * d.OH * d.OW * 4 >= (1ll << 31)) {      // the epilogue addresses one sample's output with 32-bit offsets
+        *err = "output of one sample too large for 32-bit buffer offsets"; return false;
+    }
 
     int max_wtaps = 0;
     for (int a = 0; a < pl->h.nphase; ++a) {
