@@ -369,6 +369,26 @@ def test_udss_blocks_and_errors(device):
         unet_amd.UDSS(type_norm="BatchNorm2d", type_encoder="ComplexDepthSeparable")
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 257, 37), (1, 2, 257, 130), (3, 1, 5, 64), (1, 2, 64, 501), (2, 2, 300, 33)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_over_frequency(device, shape, dtype):
+    """LayerNorm(F) of ResUNet.py:47-54 on [N,C,F,T] without the permutes: the one-read strip kernel (F <= 288) and
+    the two-pass kernel (F = 300), ragged widths, a mean far from zero, fp32 and bfloat16 storage."""
+    from unet_amd import ops
+    N, C, F, T = shape
+    g = torch.Generator().manual_seed(F * 1000 + T)
+    x = (torch.randn(N, C, F, T, generator=g) * 0.7 + 11.0).to(dtype)
+    ln = torch.nn.LayerNorm(F)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(F, generator=g) + 0.5)
+        ln.bias.copy_(torch.randn(F, generator=g) * 0.1)
+        want = ln(x.float().permute(0, 1, 3, 2)).permute(0, 1, 3, 2)
+    out = torch.zeros(N, C + 3, F, T, device=device, dtype=dtype)
+    ops.layernorm_f(x.to(device), ln.weight.to(device), ln.bias.to(device), ln.eps, out, 1)
+    assert_close(out[:, 1:1 + C].float(), want, tol=1e-4 if dtype == torch.float32 else 6e-3, what="layernorm over F")
+    assert out[:, :1].abs().max().item() == 0.0 and out[:, 1 + C:].abs().max().item() == 0.0
+
+
 def test_pointwise_kernels(device):
     """LayerNorm over frequency, tanh mask, complex ratio filter (3x3 taps) and the
     complex-mask product, each against its CPU restatement."""

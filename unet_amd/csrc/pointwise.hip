@@ -68,6 +68,53 @@ __global__ __launch_bounds__(256) void layernorm_f_kernel(const void* __restrict
         st_act<BF16>(out, dst + (size_t)f * T, (ld_act<BF16>(x, col + (size_t)f * T) - mean) * rstd * gamma[f] + beta[f]);
 }
 
+// The same LayerNorm with ONE read and one write of the tensor, for F <= 4 * RMAX: a workgroup owns a strip of 64
+// columns of one (n, c) plane, wave w the rows [w * ceil(F/4), (w+1) * ceil(F/4)), each lane keeps its column's
+// values of those rows in registers; the column sums cross the four waves through LDS (mean first, then the
+// squared deviations from it: the two-pass variance without a second read).  Rows are wave-uniform, so the only
+// per-lane condition is the column, carried as an out-of-range buffer offset.
+template <bool BF16, int RMAX>
+__global__ __launch_bounds__(256) void layernorm_f_strip_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, void* __restrict__ out,
+                                                                int C, int F, int T, int C_out, int c_off, float eps) {
+    constexpr int EB = BF16 ? 2 : 4;
+    __shared__ float s_red[2][4][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = blockIdx.x * 64 + lane;
+    const int nc = blockIdx.y, n = nc / C, c = nc % C;
+    const int R = (F + 3) >> 2, f0 = w * R;
+    const int plane_bytes = F * T * EB;
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(x)) + (size_t)nc * plane_bytes, 0, plane_bytes, 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        static_cast<char*>(out) + ((size_t)n * C_out + c_off + c) * plane_bytes, 0, plane_bytes, 0x00020000);
+    const int voff = t < T ? t * EB : (int)0x80000000;
+    float v[RMAX];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+        v[i] = 0.f;
+        if (i < R && f0 + i < F) v[i] = buf_ld_act<BF16>(rs_in, voff, (f0 + i) * T * EB);      // wave-uniform condition
+    }
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) sum += v[i];
+    s_red[0][w][lane] = sum;
+    __syncthreads();
+    const float mean = (s_red[0][0][lane] + s_red[0][1][lane] + s_red[0][2][lane] + s_red[0][3][lane]) / (float)F;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i)
+        if (i < R && f0 + i < F) { const float d = v[i] - mean; var = fmaf(d, d, var); }
+    s_red[1][w][lane] = var;
+    __syncthreads();
+    const float rstd = rsqrtf((s_red[1][0][lane] + s_red[1][1][lane] + s_red[1][2][lane] + s_red[1][3][lane]) / (float)F + eps);
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i)
+        if (i < R && f0 + i < F)
+            buf_st_act<BF16>((v[i] - mean) * rstd * gamma[f0 + i] + beta[f0 + i], rs_out, voff, (f0 + i) * T * EB);
+}
+
 // out[n,k,f,t] = (tanh(y[n,k,f,t]) + eps) * x[n,k,f,t], x having Cx >= K channels (first K used)
 template <bool BF16>
 __global__ __launch_bounds__(256) void tanh_mask_kernel(const void* __restrict__ y, const void* __restrict__ x,
@@ -186,7 +233,15 @@ int unetmi_layernorm_f_fwd(int N, int C, int F, int T, int C_out, int c_off, flo
     if (N == 0) return UNETMI_OK;
     if (!x || !gamma || !beta || !out) return api_fail(UNETMI_E_BAD_ARG, "layernorm: null tensor pointer");
     if ((long long)N * C > 65535) return api_fail(UNETMI_E_UNSUPPORTED, "layernorm: N*C > 65535");
-    if (dtype == UNETMI_DTYPE_BF16)
+    constexpr int kRows = 72;                      // rows per wave the strip kernel holds in registers
+    const bool strip = (F + 3) / 4 <= kRows && (long long)F * T * 4 < (1ll << 31);
+    if (strip && dtype == UNETMI_DTYPE_BF16)
+        hipLaunchKernelGGL((layernorm_f_strip_kernel<true, kRows>), dim3((T + 63) / 64, N * C), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), x, gamma, beta, out, C, F, T, C_out, c_off, eps);
+    else if (strip)
+        hipLaunchKernelGGL((layernorm_f_strip_kernel<false, kRows>), dim3((T + 63) / 64, N * C), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), x, gamma, beta, out, C, F, T, C_out, c_off, eps);
+    else if (dtype == UNETMI_DTYPE_BF16)
         hipLaunchKernelGGL(layernorm_f_kernel<true>, dim3((T + 255) / 256, N * C), dim3(256), 0, static_cast<hipStream_t>(stream),
                            x, gamma, beta, out, C, F, T, C_out, c_off, eps);
     else
