@@ -324,3 +324,83 @@ def test_full_width_train_step_matches_oracle(device):
             assert_close(v.detach().cpu(), after_ref[k], tol=1e-5, what="running statistic " + k)
     print("full-width train step: loss {:.6f}; {} of {} pre-activations on the other side of zero than the oracle's; "
           "worst gradient error {:.2e} of its tensor's scale".format(loss.item(), flips[0], flips[1], worst))
+
+
+def test_dsunet_train_step_matches_oracle(device):
+    """DSUNet in train() mode (DSUNet.py:582-628 under autograd): gated encoders, concat decoders, the 1x1 head and
+    the tanh mask; loss on the complex mask's real and imaginary parts.  Every gradient -- including the attractor's
+    Linears, which the gates feed -- against float64 autograd of the oracle run with the device's activation
+    pattern (see test_full_width_train_step_matches_oracle), the BatchNorm running statistics against the fp32
+    oracle."""
+    import numpy as np
+    import torch.nn as nn
+    import oracle
+    import unet_amd
+    from unet_amd.DSUNet import Decoder as DSDecoder, Encoder as DSEncoder
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.DSUNet(oracle.dsunet_architecture(45, 8))
+    unet_amd.seeded_fill_(ref, seed=51)
+    dev = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8))
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    sf = normal("dsunet/sf_train", (2, 8, 257, 16), seed=52)
+    SV = normal("dsunet/SV_train", (2, 4, 514), seed=52)
+    ang = uniform("dsunet/theta_train", (2,), 0.0, 2 * np.pi, seed=52)
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    target = uniform("dsunet/target_train", (2, 257, 16, 2), -1.0, 1.0, seed=52)
+
+    def loss_of(net, *args, tgt):
+        return torch.mean((torch.view_as_real(net(*args)) - tgt) ** 2)
+
+    ref64 = copy.deepcopy(ref).double().train()
+    ref.train()
+    loss_ref = loss_of(ref, sf, SV, theta, tgt=target)
+
+    dev.to(device).train()
+    masks = {}
+    handles = [m.register_forward_hook(lambda mod, i, o, n=name: masks.__setitem__(n, o.detach().cpu()))
+               for name, m in dev.named_modules() if isinstance(m, (DSEncoder, DSDecoder))]
+    loss = loss_of(dev, sf.to(device), SV.to(device), theta.to(device), tgt=target.to(device))
+    loss.backward()
+    for h in handles:
+        h.remove()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    assert len(masks) == 20
+
+    flips = [0, 0]
+
+    def device_pattern(name, block):
+        def hook(mod, inp, out):
+            pre = inp[0]
+            # a block's device output is act(pre) times a positive gate (encoders): its sign is the pre-activation's
+            pattern = masks[name] >= 0
+            flips[0] += int(((pre >= 0) != pattern).sum())
+            flips[1] += pre.numel()
+            return pre * torch.where(pattern, 1.0, mod.negative_slope).to(pre.dtype)
+        return hook
+    for name, m in ref64.named_modules():
+        if isinstance(getattr(m, "relu", None), nn.LeakyReLU):
+            m.relu.inplace = False
+            m.relu.register_forward_hook(device_pattern(name, m))
+    loss_of(ref64, sf.double(), SV.double(), theta.double(), tgt=target.double()).backward()
+    assert flips[1] > 1e6 and flips[0] <= 1e-5 * flips[1], flips
+    exact = {k: p.grad for k, p in ref64.named_parameters()}
+    gmax = max(g.abs().max().item() for g in exact.values() if g is not None)
+    worst = 0.0
+    for k, p in dev.named_parameters():
+        if exact[k] is None:                       # a parameter the forward does not use (in the reference as well)
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
+            continue
+        assert p.grad is not None, k
+        g = p.grad.detach().cpu().double()
+        # the bias gradient of a convolution that feeds BatchNorm is exactly zero; what either side computes is
+        # the rounding residue of a sum over ~1e5 terms, so the floor of the scale is 1e-2 of the largest gradient
+        scale = max(exact[k].abs().max().item(), 1e-2 * gmax)
+        err = (g - exact[k]).abs().max().item()
+        worst = max(worst, err / scale)
+        assert err <= 1e-4 * scale, "grad {}: err {:.3e} of scale {:.3e}".format(k, err, scale)
+    after_ref = ref.state_dict()
+    for k, v in dev.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert_close(v.detach().cpu(), after_ref[k], tol=1e-5, what="running statistic " + k)
+    print("DSUNet train step: loss {:.6f}; {} of {} pre-activations on the other side of zero; worst gradient error "
+          "{:.2e} of its tensor's scale".format(loss.item(), flips[0], flips[1], worst))

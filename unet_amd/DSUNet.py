@@ -35,13 +35,32 @@ class _Block(nn.Module):
     def _run(self, conv, x, skip=None, gate=None):
         require_device_tensor(x, type(self).__name__)
         if self.training:
-            raise NotImplementedError("{}: train-mode forward is not available in this build; call .eval()"
-                                      .format(type(self).__name__))
+            return self._run_differentiable(conv, x, skip, gate)
         if self._fused is None:
             object.__setattr__(self, "_fused", FusedConv(conv, self.bn, self.relu))
         if self._fused.fusable():
             return self._fused(x, skip, gate=gate)
         y = self.relu(self.bn(self._fused(x, skip, epilogue=False)))
+        return y if gate is None else y * gate[:, :, None, None]
+
+
+    def _run_differentiable(self, conv, x, skip, gate):
+        """train() mode (the reference's blocks are trained under stock autograd, DSUNet.py:62-93, :174-200):
+        convolution, BatchNorm with batch statistics and activation are one autograd node whose forward and
+        backward are HIP launches (unet_amd/train.py); the gate product stays a torch operation, so its gradient
+        reaches the attractor's Linears."""
+        from .train import conv_norm_act
+        who = type(self).__name__
+        found = activation_code(self.relu)
+        if not isinstance(self.bn, nn.BatchNorm2d) or found is None or isinstance(found[1], torch.Tensor):
+            raise NotImplementedError("{}: train-mode forward is built for BatchNorm2d with LeakyReLU / SiLU / Softplus "
+                                      "(got {} / {})".format(who, type(self.bn).__name__, type(self.relu).__name__))
+        drop = getattr(self, "dr", None)
+        if drop is not None and drop.p != 0.0:
+            raise NotImplementedError("{}: dropout with p > 0 is not built".format(who))
+        code, par = found
+        act_param = None if par is None else torch.full((1,), par, dtype=torch.float32, device=x.device)
+        y = conv_norm_act(conv, self.bn, code, act_param, x, skip)
         return y if gate is None else y * gate[:, :, None, None]
 
 
@@ -389,6 +408,13 @@ class DSUNet(nn.Module):
         p = self.BTN(sf)
         for i, dec in enumerate(self.decoders):
             p = dec(p) if i == 0 else dec(p, skips[L - i])
+        if self.training:
+            # differentiable head: the 1x1 convolution is an autograd node over HIP launches, the squash is torch's
+            from .train import conv_norm_act
+            m = conv_norm_act(self.linear, None, _lib.ACT_NONE, None, p)
+            if self.mask.squash is not None:
+                m = self.mask.squash(m)
+            return torch.complex(m[:, 0, ...], m[:, 1, ...])
         if self._head is None:
             object.__setattr__(self, "_head", FusedConv(self.linear, None, self.mask.squash))
         m = self._head(p).float()                                      # [B, 2, F, T], squashed (complex64 output)

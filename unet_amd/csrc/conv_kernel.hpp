@@ -100,6 +100,9 @@ __device__ __forceinline__ void mfma_rows(f32x16 (&acc)[TPG], float (&a)[2], flo
             __builtin_amdgcn_sched_barrier(0);
         }
         side();      // one piece of staging work per tap, issued in the shadow of the MFMAs above
+#ifdef UNETMI_SIDE2
+        side();      // probe: two per tap, so a chunk's DMA is all issued in the first half of the tap walk
+#endif
     }
 }
 
@@ -207,6 +210,9 @@ __device__ __forceinline__ void mfma_rows2(f32x16 (&acc0)[TPG], f32x16 (&acc1)[T
             __builtin_amdgcn_sched_barrier(0);
         }
         side();
+#ifdef UNETMI_SIDE2
+        side();
+#endif
     }
 }
 
