@@ -328,6 +328,14 @@ int unetmi_adam_step(size_t n, float* param, const float* grad, float* exp_avg, 
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
                      void* stream);
 
+/* Train-mode BatchNorm2d's running-statistics update (UNet_m.py:312 under train()) from the (mean, invstd) that
+ * unetmi_bn_train_stats returned for a batch of `count` values per channel:
+ *   running_mean = (1 - momentum) running_mean + momentum mean
+ *   running_var  = (1 - momentum) running_var  + momentum (1/invstd^2 - eps) count / (count - 1).
+ * For callers that keep the statistics kernel free of side effects (pass it null running pointers). */
+int unetmi_bn_running_update(int C, long long count, float eps, float momentum, const float* mean, const float* invstd,
+                             float* running_mean, float* running_var, void* stream);
+
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0 for i < n.  With the map of a layer (the element numbers that
  * unetmi_conv2d_pack_weights puts at each position of the packed image, -1 for padding; found once per layer
  * shape by packing a numbered tensor on the host) this re-packs a weight tensor on the device after every

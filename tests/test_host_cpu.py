@@ -318,6 +318,16 @@ def test_every_entry_point_is_a_dispatcher_op_with_shape_inference():
         out = ops.conv2d_b16_fwd(b, 8, None, 0, w, c, c, c, None, None, geom, [0, 0, 0, 1, 1])
         assert out.shape == (2, 4, 5, 7) and out.dtype == torch.float32
         assert ops.adam_step(c, c, c, c, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 1) is None
+        m2, i2 = ops.bn_batch_stats(z, 1e-5)
+        assert m2.shape == i2.shape == (8,)
+        assert ops.bn_running_update(c, c.clone(), m2, i2, 70, 1e-5, 0.1) is None
+        assert ops.gather_f32(c, torch.empty(12, dtype=torch.int32)).shape == (12,)
+        # the differentiable block: a functional op whose backward is registered with the dispatcher
+        w = torch.empty(4, 8, 3, 3, requires_grad=True)
+        y, zz, mm, ii = ops.conv_norm_act(z, None, w, None, torch.empty(4), torch.empty(4), None, None, geom, False, 1,
+                                          1e-5, 1, None)
+        assert y.shape == zz.shape == (2, 4, 5, 7) and mm.shape == ii.shape == (4,)
+        assert y.requires_grad and y.grad_fn is not None
 
 
 def test_blocked_conv_folds_only_eval_batchnorm_and_handles_affine_false():

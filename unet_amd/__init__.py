@@ -6,7 +6,7 @@ signatures whose device path is hand-written HIP (libunetmi.so) bound through
 loudly when it is missing: there is no CPU or eager fallback.
 """
 
-from . import _lib, ops  # noqa: F401  (loads libunetmi.so, registers torch.ops.unetmi.*)
+from . import _lib, ops, train  # noqa: F401  (loads libunetmi.so, registers torch.ops.unetmi.*)
 from .UNet_m import Encoder, Decoder, ResBlock
 from .UNet import UNet, default_unet_blocks
 from .cRFUNet import UNet20, UNet10

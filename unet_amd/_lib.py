@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "unetmi_conv2d_b16_fwd",
     "unetmi_blocked_from_nchw",
     "unetmi_nchw_from_blocked",
+    "unetmi_bn_running_update",
     "unetmi_gather_f32",
     "unetmi_comm_unique_id",
     "unetmi_comm_init",
@@ -129,6 +130,8 @@ def _load():
     lib.unetmi_blocked_from_nchw.restype = ctypes.c_int
     lib.unetmi_nchw_from_blocked.argtypes = [ci] * 3 + [fp, fp, ci, vp]
     lib.unetmi_nchw_from_blocked.restype = ctypes.c_int
+    lib.unetmi_bn_running_update.argtypes = [ci, ll, cf, cf, fp, fp, fp, fp, vp]
+    lib.unetmi_bn_running_update.restype = ctypes.c_int
     lib.unetmi_gather_f32.argtypes = [sz, fp, fp, fp, vp]
     lib.unetmi_gather_f32.restype = ctypes.c_int
     lib.unetmi_comm_unique_id.argtypes = [vp]

@@ -285,6 +285,23 @@ static int launched(const char* what) {
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
 }
 
+// running statistics of train-mode BatchNorm from a batch's (mean, invstd): var_biased = 1/invstd^2 - eps,
+// running_var takes the unbiased one (count / (count - 1)), as torch.nn.BatchNorm2d does
+__global__ __launch_bounds__(256) void bn_running_update_kernel(int C, double count, float eps, float momentum,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double is = (double)invstd[c];
+    double var = 1.0 / (is * is) - (double)eps;
+    if (var < 0.0) var = 0.0;
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+}
+
 // packed[i] = map[i] >= 0 ? weight[map[i]] : 0 -- re-packs a weight tensor into a kernel's image on the device
 // (the host-side pack is a permutation with zero padding, so it is one gather once the map is known).
 __global__ __launch_bounds__(256) void gather_kernel(size_t n, const float* __restrict__ src,
@@ -409,6 +426,15 @@ int unetmi_gather_f32(size_t n, const float* src, const int* map, float* dst, vo
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
                        src, map, dst);
     return launched("gather_f32");
+}
+
+int unetmi_bn_running_update(int C, long long count, float eps, float momentum, const float* mean, const float* invstd,
+                             float* running_mean, float* running_var, void* stream) {
+    if (C < 1 || count < 1) return api_fail(UNETMI_E_BAD_DESC, "bn_running_update: bad sizes");
+    if (!mean || !invstd || !running_mean || !running_var) return api_fail(UNETMI_E_BAD_ARG, "bn_running_update: null pointer");
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), C,
+                       (double)count, eps, momentum, mean, invstd, running_mean, running_var);
+    return launched("bn_running_update");
 }
 
 }  // extern "C"

@@ -350,6 +350,9 @@ glu = torch.ops.unetmi.glu
 # ---------------------------------------------------------------------------------------
 _LIBRARY.define("bn_train_stats(Tensor z, float eps, float momentum, Tensor(a!) running_mean, Tensor(b!) running_var)"
                 " -> (Tensor, Tensor)")
+_LIBRARY.define("bn_batch_stats(Tensor z, float eps) -> (Tensor, Tensor)")
+_LIBRARY.define("bn_running_update(Tensor(a!) running_mean, Tensor(b!) running_var, Tensor mean, Tensor invstd, int count, "
+                "float eps, float momentum) -> ()")
 _LIBRARY.define("bn_act_fwd(Tensor z, Tensor mean, Tensor invstd, Tensor gamma, Tensor beta, int act, Tensor? act_param)"
                 " -> Tensor")
 _LIBRARY.define("bn_act_bwd(Tensor dy, Tensor z, Tensor mean, Tensor invstd, Tensor gamma, Tensor beta, int act, "
@@ -397,6 +400,30 @@ def _bn_train_stats_cuda(z, eps, momentum, running_mean, running_var):
                                              _ptr(mean), _ptr(invstd), _ptr(ws), ws.numel(), _stream(z)),
               "unetmi_bn_train_stats")
     return mean, invstd
+
+
+def _bn_batch_stats_cuda(z, eps):
+    """(mean, invstd) over all but the channel axis, without touching any running statistic."""
+    _dev(z, "z", "bn_batch_stats")
+    N, C, HW = _nc_hw(z)
+    mean = torch.empty(C, dtype=torch.float32, device=z.device)
+    invstd = torch.empty_like(mean)
+    ws = workspace(z.device, _lib.lib.unetmi_bn_workspace_bytes(N, C, HW))
+    with torch.cuda.device(z.device):
+        check(_lib.lib.unetmi_bn_train_stats(N, C, HW, _ptr(z), eps, 0.0, None, None, _ptr(mean), _ptr(invstd), _ptr(ws),
+                                             ws.numel(), _stream(z)), "unetmi_bn_train_stats")
+    return mean, invstd
+
+
+def _bn_running_update_cuda(running_mean, running_var, mean, invstd, count, eps, momentum):
+    C = mean.numel()
+    for t, name in ((running_mean, "running_mean"), (running_var, "running_var"), (mean, "mean"), (invstd, "invstd")):
+        _dev(t, name, "bn_running_update")
+        if t.numel() != C:
+            raise ValueError("unetmi::bn_running_update: {} needs {} elements".format(name, C))
+    with torch.cuda.device(mean.device):
+        check(_lib.lib.unetmi_bn_running_update(C, count, eps, momentum, _ptr(mean), _ptr(invstd), _ptr(running_mean),
+                                                _ptr(running_var), _stream(mean)), "unetmi_bn_running_update")
 
 
 def _bn_act_fwd_cuda(z, mean, invstd, gamma, beta, act, act_param):
@@ -597,7 +624,8 @@ def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param
     return out
 
 
-for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_act_fwd", _bn_act_fwd_cuda),
+for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_batch_stats", _bn_batch_stats_cuda),
+                   ("bn_running_update", _bn_running_update_cuda), ("bn_act_fwd", _bn_act_fwd_cuda),
                    ("bn_act_bwd", _bn_act_bwd_cuda), ("conv2d_wgrad", _conv2d_wgrad_cuda),
                    ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda),
                    ("blocked_from_nchw", _blocked_from_nchw_cuda), ("nchw_from_blocked", _nchw_from_blocked_cuda),
@@ -608,6 +636,16 @@ for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_act_fwd", _bn_
 @torch.library.register_fake("unetmi::bn_train_stats")
 def _(z, eps, momentum, running_mean, running_var):
     return z.new_empty((z.shape[1],)), z.new_empty((z.shape[1],))
+
+
+@torch.library.register_fake("unetmi::bn_batch_stats")
+def _(z, eps):
+    return z.new_empty((z.shape[1],)), z.new_empty((z.shape[1],))
+
+
+@torch.library.register_fake("unetmi::bn_running_update")
+def _(running_mean, running_var, mean, invstd, count, eps, momentum):
+    return None
 
 
 @torch.library.register_fake("unetmi::bn_act_fwd")
@@ -665,6 +703,8 @@ def _(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, flags
 
 
 bn_train_stats = torch.ops.unetmi.bn_train_stats
+bn_batch_stats = torch.ops.unetmi.bn_batch_stats
+bn_running_update = torch.ops.unetmi.bn_running_update
 bn_act_fwd = torch.ops.unetmi.bn_act_fwd
 bn_act_bwd = torch.ops.unetmi.bn_act_bwd
 conv2d_wgrad = torch.ops.unetmi.conv2d_wgrad

@@ -3,10 +3,12 @@ data-parallel training step.
 
 The reference trains its modules with stock autograd (there is no trainer in the
 repository); here every Encoder / Decoder block in ``train()`` mode is one
-``torch.autograd.Function`` whose forward and backward are HIP launches:
+dispatcher op (``torch.ops.unetmi.conv_norm_act``, backward registered with
+``torch.library.register_autograd``) whose forward and backward are HIP launches:
 
     forward   conv (unetmi_conv2d_fwd, no epilogue) -> batch statistics
               (unetmi_bn_train_stats) -> normalise + activation (unetmi_bn_act_fwd)
+              [-> running statistics (unetmi_bn_running_update)]
     backward  unetmi_bn_act_bwd -> weight gradient (unetmi_conv2d_wgrad) and input
               gradient (unetmi_conv2d_fwd on the gradient with the transposed flag
               flipped: same weight tensor, conv <-> transposed conv)
@@ -143,72 +145,101 @@ def _input_gradient(dz, weight, geom, transposed, in_hw):
     return dx
 
 
-class ConvNormAct(torch.autograd.Function):
-    """y = act(norm(conv(cat(x, skip)))) with train-mode BatchNorm2d (batch statistics), eval-mode
-    BatchNorm2d (running statistics, still differentiable) or no norm."""
+# ---------------------------------------------------------------------------------------
+# unetmi::conv_norm_act -- the differentiable fused block as ONE dispatcher op:
+#   y = act(norm(conv(cat(x, skip))))     norm_mode 0: none, 1: BatchNorm2d with batch statistics,
+#                                          2: BatchNorm2d with its running statistics (still differentiable)
+# Functional (it returns the batch statistics instead of updating anything), so its backward is registered with
+# torch.library.register_autograd; the running-statistics update is a separate op (bn_running_update).
+# Outputs: y, and what the backward needs -- z (the convolution output), mean, invstd.
+# ---------------------------------------------------------------------------------------
+_ops._LIBRARY.define(
+    "conv_norm_act(Tensor x, Tensor? skip, Tensor weight, Tensor? bias, Tensor? gamma, Tensor? beta, "
+    "Tensor? running_mean, Tensor? running_var, int[] geom, bool transposed, int norm_mode, float eps, int act, "
+    "Tensor? act_param) -> (Tensor, Tensor, Tensor, Tensor)")
 
-    @staticmethod
-    def forward(ctx, x, skip, weight, bias, gamma, beta, cfg):
-        geom, transposed = cfg["geom"], cfg["transposed"]
-        z = _plain_conv(x, skip, weight, bias, geom, transposed)
-        K = geom[0]
-        dev = z.device
-        bn = cfg["bn"]
-        if bn is not None and cfg["batch_stats"]:
-            mean, invstd = bn_train_stats(z, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
-            # the kernel wrote the running statistics through raw pointers: tell torch they changed
-            torch.autograd.graph.increment_version(bn.running_mean)
-            torch.autograd.graph.increment_version(bn.running_var)
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
-        elif bn is not None:
-            mean = bn.running_mean.detach()
-            invstd = torch.rsqrt(bn.running_var.detach() + bn.eps)
+
+def _conv_norm_act_cuda(x, skip, weight, bias, gamma, beta, running_mean, running_var, geom, transposed, norm_mode,
+                        eps, act, act_param):
+    z = _plain_conv(x, skip, weight, bias, geom, transposed)
+    K, dev = geom[0], z.device
+    if norm_mode == 1:
+        mean, invstd = _ops.bn_batch_stats(z, eps)
+    elif norm_mode == 2:
+        mean = running_mean.detach()
+        invstd = torch.rsqrt(running_var.detach() + eps)
+    else:
+        mean, invstd = _constant(0.0, K, dev), _constant(1.0, K, dev)
+    g = gamma.detach() if gamma is not None else _constant(1.0, K, dev)
+    b = beta.detach() if beta is not None else _constant(0.0, K, dev)
+    y = _ops.bn_act_fwd(z, mean, invstd, g, b, act, act_param)
+    # mean / invstd may be cached constants or views of module buffers: outputs of an op must be its own tensors
+    if norm_mode != 1:
+        mean, invstd = mean.clone(), invstd.clone()
+    return y, z, mean, invstd
+
+
+_ops._LIBRARY.impl("conv_norm_act", _conv_norm_act_cuda, "CUDA")
+
+
+@torch.library.register_fake("unetmi::conv_norm_act")
+def _(x, skip, weight, bias, gamma, beta, running_mean, running_var, geom, transposed, norm_mode, eps, act, act_param):
+    N, _, H, W = x.shape
+    K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
+    z = x.new_empty((N, K, conv_out_size(H, kh, sh, ph, dh, oph, transposed), conv_out_size(W, kw, sw, pw, dw, opw, transposed)))
+    return torch.empty_like(z), z, x.new_empty((K,)), x.new_empty((K,))
+
+
+def _conv_norm_act_setup(ctx, inputs, output):
+    x, skip, weight, bias, gamma, beta, _, _, geom, transposed, norm_mode, _, act, act_param = inputs
+    _, z, mean, invstd = output
+    ctx.geom, ctx.transposed, ctx.norm_mode, ctx.act = list(geom), bool(transposed), norm_mode, act
+    ctx.in_hw, ctx.c0 = tuple(x.shape[2:]), x.shape[1]
+    ctx.has = (skip is not None, bias is not None, gamma is not None, beta is not None, act_param is not None)
+    ctx.set_materialize_grads(False)           # z / mean / invstd are outputs only so that they can be saved
+    ctx.save_for_backward(x, skip, weight, z, mean, invstd, gamma, beta, act_param)
+
+
+def _conv_norm_act_backward(ctx, dy, dz_unused, dmean_unused, dinvstd_unused):
+    x, skip, weight, z, mean, invstd, gamma, beta, act_param = ctx.saved_tensors
+    none = (None,) * 8
+    if dy is None:
+        return (None,) * 6 + none
+    geom, transposed = ctx.geom, ctx.transposed
+    need = ctx.needs_input_grad
+    K, dev = geom[0], z.device
+    g = gamma.detach() if gamma is not None else _constant(1.0, K, dev)
+    b = beta.detach() if beta is not None else _constant(0.0, K, dev)
+    dz, dgamma, dbeta, dbias = bn_act_bwd(dy, z, mean, invstd, g, b, ctx.act, act_param, ctx.norm_mode == 1)
+    dweight = None
+    if need[2]:
+        N, C0, H, W = x.shape
+        C1 = skip.shape[1] if skip is not None else 0
+        d = make_desc(N, C0, C1, H, W, geom, [int(transposed), _lib.IN_CONCAT if C1 else _lib.IN_SINGLE, 0, 0])
+        if transposed or skip is None:
+            dweight = conv2d_wgrad(d, x, skip, dz)
+        else:                                   # plain conv over a concatenation: not a case these models have
+            d = make_desc(N, C0 + C1, 0, H, W, geom, [0, _lib.IN_SINGLE, 0, 0])
+            dweight = conv2d_wgrad(d, torch.cat([x, skip], 1), None, dz)
+    dx = dskip = None
+    if need[0] or (skip is not None and need[1]):
+        dcat = _input_gradient(dz, weight, geom, transposed, ctx.in_hw)
+        if skip is None:
+            dx = dcat
         else:
-            mean, invstd = _constant(0.0, K, dev), _constant(1.0, K, dev)
-        g = gamma.detach() if gamma is not None else _constant(1.0, K, dev)
-        b = beta.detach() if beta is not None else _constant(0.0, K, dev)
-        y = bn_act_fwd(z, mean, invstd, g, b, cfg["act"], cfg["act_param"])
-        ctx.cfg = cfg
-        ctx.in_hw = tuple(x.shape[2:])
-        ctx.c0 = x.shape[1]
-        ctx.has_affine = (gamma is not None, beta is not None)
-        ctx.save_for_backward(x, skip, weight, z, mean, invstd, g, b)
-        return y
+            dx, dskip = dcat[:, :ctx.c0], dcat[:, ctx.c0:]
+    return (dx if need[0] else None, dskip if (ctx.has[0] and need[1]) else None, dweight,
+            dbias if (ctx.has[1] and need[3]) else None, dgamma if (ctx.has[2] and need[4]) else None,
+            dbeta if (ctx.has[3] and need[5]) else None) + none
 
-    @staticmethod
-    def backward(ctx, dy):
-        x, skip, weight, z, mean, invstd, g, b = ctx.saved_tensors
-        cfg = ctx.cfg
-        geom, transposed = cfg["geom"], cfg["transposed"]
-        need = ctx.needs_input_grad
-        dz, dgamma, dbeta, dbias = bn_act_bwd(dy, z, mean, invstd, g, b, cfg["act"], cfg["act_param"],
-                                              cfg["bn"] is not None and cfg["batch_stats"])
-        dweight = None
-        if need[2]:
-            N, C0, H, W = x.shape
-            C1 = skip.shape[1] if skip is not None else 0
-            d = make_desc(N, C0, C1, H, W, geom, [int(transposed), _lib.IN_CONCAT if C1 else _lib.IN_SINGLE, 0, 0])
-            if transposed or skip is None:
-                dweight = conv2d_wgrad(d, x, skip, dz)
-            else:                                   # plain conv over a concatenation: not a case these models have
-                d = make_desc(N, C0 + C1, 0, H, W, geom, [0, _lib.IN_SINGLE, 0, 0])
-                dweight = conv2d_wgrad(d, torch.cat([x, skip], 1), None, dz)
-        dx = dskip = None
-        if need[0] or (skip is not None and need[1]):
-            dcat = _input_gradient(dz, weight, geom, transposed, ctx.in_hw)
-            if skip is None:
-                dx = dcat
-            else:
-                dx, dskip = dcat[:, :ctx.c0], dcat[:, ctx.c0:]
-        return (dx if need[0] else None, dskip if need[1] else None, dweight,
-                dbias if need[3] else None, dgamma if (ctx.has_affine[0] and need[4]) else None,
-                dbeta if (ctx.has_affine[1] and need[5]) else None, None)
+
+torch.library.register_autograd("unetmi::conv_norm_act", _conv_norm_act_backward, setup_context=_conv_norm_act_setup)
 
 
 def conv_norm_act(conv, norm, act_code, act_param, x, skip=None):
     """Differentiable fused block for nn.Conv2d / nn.ConvTranspose2d ``conv`` followed by ``norm``
-    (nn.BatchNorm2d, nn.Identity or None) and an activation given by its epilogue code."""
+    (nn.BatchNorm2d, nn.Identity or None) and an activation given by its epilogue code: one
+    ``torch.ops.unetmi.conv_norm_act`` node, then the BatchNorm bookkeeping that a train-mode forward does."""
     from .fused import FusedConv
     geom, transposed = FusedConv(conv).geometry()
     bn = norm if isinstance(norm, nn.BatchNorm2d) else None
@@ -220,11 +251,21 @@ def conv_norm_act(conv, norm, act_code, act_param, x, skip=None):
     batch_stats = bn is not None and (bn.training or bn.running_mean is None)
     if bn is not None and batch_stats and (bn.momentum is None or not bn.track_running_stats):
         raise NotImplementedError("train-mode BatchNorm2d needs a numeric momentum and tracked running statistics")
-    cfg = dict(geom=geom, transposed=bool(transposed), bn=bn, batch_stats=batch_stats, act=act_code,
-               act_param=act_param)
-    gamma = bn.weight if bn is not None else None
-    beta = bn.bias if bn is not None else None
-    return ConvNormAct.apply(x, skip, conv.weight, conv.bias, gamma, beta, cfg)
+    mode = 0 if bn is None else (1 if batch_stats else 2)
+    y, z, mean, invstd = torch.ops.unetmi.conv_norm_act(
+        x, skip, conv.weight, conv.bias, bn.weight if bn is not None else None, bn.bias if bn is not None else None,
+        bn.running_mean if mode == 2 else None, bn.running_var if mode == 2 else None, list(geom), bool(transposed),
+        mode, bn.eps if bn is not None else 0.0, act_code, act_param)
+    if mode == 1:
+        with torch.no_grad():
+            count = z.numel() // z.shape[1]
+            _ops.bn_running_update(bn.running_mean, bn.running_var, mean, invstd, count, bn.eps, bn.momentum)
+            # written through raw pointers: tell torch they changed
+            torch.autograd.graph.increment_version(bn.running_mean)
+            torch.autograd.graph.increment_version(bn.running_var)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+    return y
 
 
 # ---------------------------------------------------------------------------------------
