@@ -372,11 +372,13 @@ _ws_cache = {}
 
 
 def workspace(device, nbytes):
-    """One growing scratch buffer per device (contents never outlive a launch sequence)."""
-    buf = _ws_cache.get(device)
+    """One growing scratch buffer per (device, stream): its contents never outlive a launch sequence, and work on
+    different streams never shares one."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[device] = buf
+        _ws_cache[key] = buf
     return buf
 
 
