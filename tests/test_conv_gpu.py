@@ -200,3 +200,50 @@ def test_pointwise_64_encoder_block(device, act, shape):
     x = normal("pw64/x", shape, seed=61)
     with torch.no_grad():
         assert_close(dev(x.to(device)), ref(x), what="pointwise 64->64 block")
+
+
+UPCONV_CASES = [
+    # (N, H, W, pad, out_pad, activation, act_first, gate, residual)
+    (3, 7, 29, 1, 1, "prelu", True, False, True),          # ResUNet's decoder layer (PReLU then BatchNorm, skip added)
+    (8, 15, 130, 1, 1, "prelu", True, False, True),        # batch multiple of 8: the by-XCD tile order
+    (2, 1, 64, 0, 0, "prelu64", False, False, False),      # one input row, per-channel slopes, norm then activation
+    (1, 5, 1, 0, 1, "leaky", False, True, True),           # one column, gate and added tensor
+    (2, 6, 67, 1, 0, "relu", False, False, True),
+    (1, 9, 70, 0, 0, "none", False, False, False),
+    (2, 4, 33, 1, 1, "silu", True, True, True),            # an activation without a slope form
+    (16, 31, 501, 1, 1, "prelu", True, False, True),       # the benchmark's width, many tiles per workgroup
+]
+
+
+@pytest.mark.parametrize("case", UPCONV_CASES, ids=lambda c: "N{}H{}W{}p{}op{}{}".format(*c[:6]))
+def test_frequency_doubling_decoder_layer(device, case):
+    """ConvTranspose2d(64, 64, (4,1), stride (2,1)) -- ResUNet.py:88-89, the layer that carries the folded skip add:
+    both paddings and output paddings, ragged and degenerate sizes, every epilogue form, against the torch CPU ops."""
+    from unet_amd.fused import FusedConv
+    N, H, W, pad, opad, act_name, act_first, with_gate, with_res = case
+    act = {"prelu": nn.PReLU(), "prelu64": nn.PReLU(64), "leaky": nn.LeakyReLU(0.2), "relu": nn.ReLU(),
+           "none": nn.Identity(), "silu": nn.SiLU()}[act_name]
+    conv = nn.ConvTranspose2d(64, 64, (4, 1), (2, 1), (pad, 0), output_padding=(opad, 0))
+    bn = nn.BatchNorm2d(64)
+    mods = nn.ModuleList([conv, bn, act]).eval()
+    _fill(mods, 400 + H)
+    if act_name == "prelu64":
+        with torch.no_grad():
+            act.weight.copy_(torch.linspace(-0.3, 0.6, 64))
+    x = _seeded((N, 64, H, W), 31 + W, 1.5)
+    with torch.no_grad():
+        y = conv(x)
+        y = bn(act(y)) if act_first else act(bn(y))
+    gate = torch.rand(N, 64, generator=torch.Generator().manual_seed(4)) if with_gate else None
+    res = _seeded(tuple(y.shape), 8) if with_res else None
+    want = y
+    if gate is not None:
+        want = want * gate[:, :, None, None]
+    if res is not None:
+        want = want + res
+    mods.to(device)
+    got = FusedConv(mods[0], mods[1], mods[2], act_first=act_first)(
+        x.to(device), gate=None if gate is None else gate.to(device), residual=None if res is None else res.to(device))
+    assert tuple(got.shape) == tuple(want.shape)
+    assert_close(got, want, what="frequency-doubling layer " + act_name)
+    mods.cpu()
