@@ -131,7 +131,9 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
         pl->lds_bytes = 0;
         return true;
     }
-    pl->NB = (d.K <= 32) ? 32 : 64;
+    // 64 output channels per workgroup, or 32 when that pads the channel count less (K = 90: 3 x 32 = 96 against
+    // 2 x 64 = 128 -- a quarter of the matrix work of a 64-wide second block would be on padding)
+    pl->NB = (d.K <= 32 || (d.K + 31) / 32 * 32 < (d.K + 63) / 64 * 64) ? 32 : 64;
     pl->nco_blk = (d.K + pl->NB - 1) / pl->NB;
     pl->WN = pl->NB / 32; pl->WM = kWaves / pl->WN;
     pl->NG = pl->w.nphase; pl->TPG = 4;
