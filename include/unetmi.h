@@ -196,10 +196,14 @@ int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float*
  * device of 8 XCDs x 32 compute units with one workgroup resident per compute unit (UNETMI_E_UNSUPPORTED
  * otherwise: use unetmi_lstm_recurrence).  A workgroup finds its XCD from the hardware, not from its index.
  * Status: ((uint32_t*)ws)[8] is non-zero after an aborted run (a workgroup was not resident, e.g. the GPU is
- * shared); every slot of hfull from the aborted step on is then NaN. */
+ * shared); every slot of hfull from the aborted step on is then NaN.
+ * channel_major = 1 takes gx as [4H][T+1][BP] (slot t+1 = step t; slot 0 is not read) and writes hfull as
+ * [H][T+1][BP]: the layouts in which the two matrix products around the recurrence are 1x1 convolutions of
+ * unetmi_conv2d_fwd over a [channels, T+1, BP] image (gx = W_ih * x + b; h = W_hr * hfull), so a layer's output
+ * is the next layer's input without a transpose. */
 size_t unetmi_lstm_recurrence_xcd_workspace_bytes(void);
-int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, void* ws,
-                               size_t ws_bytes, void* stream);
+int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wrec, const float* gx, float* hfull,
+                               int channel_major, void* ws, size_t ws_bytes, void* stream);
 
 /* LayerNorm over the FREQUENCY axis of x[N,C,F,T] (biased variance, affine gamma/beta[F]),
  * written into channels [c_off, c_off+C) of out[N,C_out,F,T].  Replaces

@@ -308,7 +308,7 @@ def test_every_entry_point_is_a_dispatcher_op_with_shape_inference():
         assert dz.shape == z.shape and dg.shape == db.shape == dbias.shape == (8,)
         assert ops.conv2d_wgrad(z, None, torch.empty(2, 4, 5, 7), geom, [0, 0]).shape == (4, 8, 3, 3)
         assert ops.conv2d_wgrad(z, None, torch.empty(2, 4, 5, 7), geom, [1, 0]).shape == (8, 4, 3, 3)
-        status = ops.lstm_recurrence(torch.empty(2560, 640), torch.empty(5, 2560, 16), torch.empty(6, 640, 16), True)
+        status = ops.lstm_recurrence(torch.empty(2560, 640), torch.empty(5, 2560, 16), torch.empty(6, 640, 16), True, False)
         assert status.shape == () and status.dtype == torch.int32
         b = ops.blocked_from_nchw(z)
         assert b.shape == (2, 2, 5, 7, 8) and b.dtype == torch.bfloat16

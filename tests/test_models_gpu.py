@@ -441,16 +441,18 @@ def test_resblock_64_one_launch_per_layer(device, shape, with_add):
     assert_close(got, want, what="ResBlock(64) fused layers")
 
 
-@pytest.mark.parametrize("kernel", ["xcd", "grid"])
+@pytest.mark.parametrize("kernel,gemm", [("xcd", "conv"), ("xcd", "blas"), ("grid", "blas")])
 @pytest.mark.parametrize("B,T", [(1, 16), (5, 37), (32, 12), (40, 9)])
-def test_projected_lstm_matches_torch_cpu(device, B, T, kernel, monkeypatch):
+def test_projected_lstm_matches_torch_cpu(device, B, T, kernel, gemm, monkeypatch):
     """ResUNet's bottleneck LSTM(384, 640, 3, proj_size=384) through both persistent recurrence kernels (batch
-    split over the XCDs / one device-wide barrier per step) against torch's CPU LSTM (the arithmetic the
-    reference uses)."""
+    split over the XCDs / one device-wide barrier per step), the XCD one with the products around the recurrence
+    as the library's own 1x1 convolutions on the channel-major layout (the default) and as torch.matmul on the
+    step-major one, against torch's CPU LSTM (the arithmetic the reference uses)."""
     import unet_amd
     import unet_amd.lstm
     from unet_amd.lstm import lstm_forward, supported
     monkeypatch.setattr(unet_amd.lstm, "KERNEL", kernel)
+    monkeypatch.setattr(unet_amd.lstm, "GEMM", gemm)
     from unet_amd.seeding import normal
     ref = torch.nn.LSTM(384, 640, 3, batch_first=True, proj_size=384)
     holder = torch.nn.Module()

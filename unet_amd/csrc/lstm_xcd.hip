@@ -47,11 +47,13 @@ constexpr unsigned kXSpinLimit = 1u << 20;
 
 struct LstmXcdArgs {
     const float* wrec;          // [4H][H]
-    const float* gx;            // [T][4H][BP]
-    float* hfull;               // [T+1][H][BP]
+    const float* gx;            // step-major [T][4H][BP], or channel-major [4H][T+1][BP] (row t+1 = step t)
+    float* hfull;               // step-major [T+1][H][BP], or channel-major [H][T+1][BP]
     unsigned* ctl;              // [8] tickets, [8] abort word (+ padding to 64 words)
     unsigned long long* hx;     // [8 XCDs][2 parities][H][4] granules {float value, unsigned step}
     int T, BP;
+    long long gx_step, gx_row, gx_first;      // element strides of gx per step / per gate row, offset of step 0
+    long long h_step, h_row;                  // element strides of hfull per step slot / per hidden unit
 };
 
 __device__ __forceinline__ float sigmoid_x(float x) { return 1.f / (1.f + expf(-x)); }
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
         if (gate_thread && col_live) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                gxv[g] = a.gx[((size_t)t * 4 * kXH + g * kXH + u_base + ul) * a.BP + col0 + cj];
+                gxv[g] = a.gx[a.gx_first + t * a.gx_step + (g * kXH + u_base + ul) * a.gx_row + col0 + cj];
         }
         // ---- this wave's quarter of h_t: granules (160*wave + e/4, e%4), e = lane + 64*i, until all read step t ----
         const unsigned long long* src = hx + (size_t)(t & 1) * kXH * kXCols + (size_t)wave * 160 * kXCols;
@@ -180,13 +182,13 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
             // XCD ever reads these granules
             __hip_atomic_store(&hx[(size_t)((t + 1) & 1) * kXH * kXCols + (size_t)(u_base + ul) * kXCols + cj], granule,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (col_live) a.hfull[((size_t)(t + 1) * kXH + u_base + ul) * a.BP + col0 + cj] = hn;
+            if (col_live) a.hfull[(t + 1) * a.h_step + (u_base + ul) * a.h_row + col0 + cj] = hn;
         }
     }
     // Aborted at step t: every state row from that step on is NaN so that nothing computed from a state that was
     // never exchanged can pass for a result (the abort word stays raised for the caller as well).
     if (t < a.T && gate_thread && col_live)
-        for (int tt = t + 1; tt <= a.T; ++tt) a.hfull[((size_t)tt * kXH + u_base + ul) * a.BP + col0 + cj] = __builtin_nanf("");
+        for (int tt = t + 1; tt <= a.T; ++tt) a.hfull[tt * a.h_step + (u_base + ul) * a.h_row + col0 + cj] = __builtin_nanf("");
 }
 
 }  // namespace unetmi
@@ -198,8 +200,9 @@ extern "C" size_t unetmi_lstm_recurrence_xcd_workspace_bytes(void) {
 }
 
 extern "C" int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wrec, const float* gx, float* hfull,
-                                          void* ws, size_t ws_bytes, void* stream) {
+                                          int channel_major, void* ws, size_t ws_bytes, void* stream) {
     if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence_xcd: bad sizes");
+    if (channel_major != 0 && channel_major != 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence_xcd: layout is 0 or 1");
     if (H != kXH) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: built for hidden size 640");
     if (BP > kXcds * kXCols) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: at most 32 batch columns per launch");
     if (T == 0) return UNETMI_OK;
@@ -217,6 +220,13 @@ extern "C" int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wre
     if (per_cu < 1) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: the kernel does not fit a compute unit");
     LstmXcdArgs a{};
     a.wrec = wrec; a.gx = gx; a.hfull = hfull; a.T = T; a.BP = BP;
+    if (channel_major) {        // [rows][T+1][BP]: slot 0 of both is the state before the first step
+        a.gx_step = BP; a.gx_row = (long long)(T + 1) * BP; a.gx_first = BP;
+        a.h_step = BP; a.h_row = (long long)(T + 1) * BP;
+    } else {
+        a.gx_step = (long long)4 * kXH * BP; a.gx_row = BP; a.gx_first = 0;
+        a.h_step = (long long)kXH * BP; a.h_row = BP;
+    }
     a.ctl = static_cast<unsigned*>(ws);
     a.hx = reinterpret_cast<unsigned long long*>(static_cast<unsigned*>(ws) + 64);
     hipStream_t s = static_cast<hipStream_t>(stream);

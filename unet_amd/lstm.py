@@ -1,9 +1,11 @@
 """Projected LSTM on the device (the bottleneck of ResUNet, ResUNet.py:139,186-197).
 
-Everything without a time dependency is a large GEMM (torch.matmul = the ROCm BLAS library):
-the input contribution of all time steps before the recurrence, the projection of all
-pre-projection states after it.  The recurrence itself is one persistent HIP launch per
-layer (unetmi_lstm_recurrence) instead of three launches per time step.
+Everything without a time dependency is a large matrix product: the input contribution of all time
+steps before the recurrence, the projection of all pre-projection states after it.  With the XCD
+kernel they are 1x1 convolutions of the library's own kernel on a [channels, T+1, BP] layout that
+the recurrence kernel reads and writes directly (``GEMM = "conv"``); the device-wide-barrier kernel
+keeps the step-major layout and torch.matmul.  The recurrence itself is one persistent HIP launch per
+layer (unetmi_lstm_recurrence_xcd / unetmi_lstm_recurrence) instead of three launches per time step.
 """
 
 import torch
@@ -42,10 +44,64 @@ def _xcd_kernel_fits(dev):
     return KERNEL == "xcd" and torch.cuda.get_device_properties(dev).multi_processor_count == 256
 
 
-def _recurrence(wrec, gx, hfull, use_xcd):
+def _recurrence(wrec, gx, hfull, use_xcd, channel_major=False):
     """One layer's T dependent steps (torch.ops.unetmi.lstm_recurrence); returns the kernel's status word
     (a device scalar, non-zero = aborted)."""
-    return _ops.lstm_recurrence(wrec, gx, hfull, bool(use_xcd))
+    return _ops.lstm_recurrence(wrec, gx, hfull, bool(use_xcd), bool(channel_major))
+
+
+# The two matrix products around the recurrence -- the input contributions of all steps, and the projection of all
+# pre-projection states -- as 1x1 convolutions of the library's own kernel over a [channels, T+1, BP] image
+# ("conv"), or as torch.matmul, i.e. the ROCm BLAS library ("blas": the step-major layout; what the device-wide-
+# barrier kernel uses).
+GEMM = "conv"
+_pointwise_cache = {}
+
+
+def _pointwise(weight, bias, cache, key):
+    """FusedConv of a [K, C] matrix as a 1x1 convolution (+ bias), cached on the parameters' versions."""
+    from .fused import FusedConv
+    ver = (weight._version, weight.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()))
+    hit = cache.get(key)
+    if hit is None or hit[0] != ver:
+        K, C = weight.shape
+        conv = nn.Conv2d(C, K, 1, bias=bias is not None).to(weight.device)
+        with torch.no_grad():
+            conv.weight.copy_(weight.detach().reshape(K, C, 1, 1))
+            if bias is not None:
+                conv.bias.copy_(bias.detach())
+        cache[key] = hit = (ver, FusedConv(conv))
+    return hit[1]
+
+
+def _forward_channel_major(lstm, x, cache):
+    """x [B, T, input] -> [B, T, proj] with every tensor of the layer stack kept as [channels, T+1, BP] (slot 0 =
+    the time before the first step): the products are 1x1 convolutions, a layer's projected output is the next
+    layer's input as it stands, and the recurrence kernel reads and writes that layout directly."""
+    B, T, C = x.shape
+    H = lstm.hidden_size
+    BP = (B + 15) // 16 * 16
+    dev = x.device
+    seq = torch.zeros((1, C, T + 1, BP), dtype=torch.float32, device=dev)
+    seq[0, :, 1:, :B] = x.permute(2, 1, 0)
+    aborted = torch.zeros((), dtype=torch.int32, device=dev)
+    for layer in range(lstm.num_layers):
+        w_ih = getattr(lstm, "weight_ih_l{}".format(layer))
+        w_hr = getattr(lstm, "weight_hr_l{}".format(layer))
+        b_ih, b_hh = getattr(lstm, "bias_ih_l{}".format(layer)), getattr(lstm, "bias_hh_l{}".format(layer))
+        bkey = ("bias", layer)
+        bver = (b_ih._version, b_ih.data_ptr(), b_hh._version, b_hh.data_ptr())
+        bhit = cache.get(bkey)
+        if bhit is None or bhit[0] != bver:
+            cache[bkey] = bhit = (bver, (b_ih.detach().float() + b_hh.detach().float()))
+        gx = _pointwise(w_ih, bhit[1], cache, ("ih", layer))(seq)                 # [1, 4H, T+1, BP]
+        wrec = _folded_recurrent_matrix(lstm, layer, cache)
+        hfull = torch.empty((1, H, T + 1, BP), dtype=torch.float32, device=dev)
+        hfull[0, :, 0].zero_()
+        aborted = aborted | _recurrence(wrec, gx[0], hfull[0], True, channel_major=True)
+        seq = _pointwise(w_hr, None, cache, ("hr", layer))(hfull)                  # [1, proj, T+1, BP]
+    out = seq[0, :, 1:, :B].permute(2, 1, 0).contiguous()
+    return torch.where(aborted != 0, torch.full_like(out, float("nan")), out)
 
 
 def lstm_forward(lstm, x, cache):
@@ -59,6 +115,9 @@ def lstm_forward(lstm, x, cache):
     group = XCD_BATCH_PER_LAUNCH if use_xcd else MAX_BATCH_PER_LAUNCH
     if B > group:                                   # sequences are independent: run them in groups
         return torch.cat([lstm_forward(lstm, x[i:i + group], cache) for i in range(0, B, group)], dim=0)
+    if use_xcd and GEMM == "conv":
+        with torch.no_grad(), torch.cuda.device(x.device):
+            return _forward_channel_major(lstm, x, cache)
     H = lstm.hidden_size
     BP = (B + 15) // 16 * 16
     dev = x.device

@@ -361,7 +361,7 @@ _LIBRARY.define("conv2d_wgrad(Tensor in0, Tensor? in1, Tensor dout, int[] geom, 
 _LIBRARY.define("adam_step(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, "
                 "float beta2, float eps, float weight_decay, float grad_scale, int step) -> ()")
 _LIBRARY.define("gather_f32(Tensor src, Tensor map) -> Tensor")
-_LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool xcd) -> Tensor")
+_LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool xcd, bool channel_major) -> Tensor")
 _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
 _LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
 _LIBRARY.define("conv2d_b16_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
@@ -512,16 +512,24 @@ def _gather_f32_cuda(src, map):
 _lstm_scratch = {}
 
 
-def _lstm_recurrence_cuda(wrec, gx, hfull, xcd):
-    """One layer's T dependent steps on gx [T, 4H, BP] (input contributions + bias) with the folded recurrent matrix
-    wrec [4H, H]; fills hfull[1:] ([T+1, H, BP], row 0 = initial state).  Returns the kernel's status word as a
-    device scalar (non-zero: a wait gave up and the remaining steps are NaN)."""
+def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major):
+    """One layer's T dependent steps with the folded recurrent matrix wrec [4H, H].  Step-major: gx [T, 4H, BP]
+    (input contributions + bias), hfull [T+1, H, BP] (slot 0 = initial state, slots 1.. are filled).  Channel-major
+    (XCD kernel only): gx [4H, T+1, BP] with slot t+1 = step t, hfull [H, T+1, BP].  Returns the kernel's status
+    word as a device scalar (non-zero: a wait gave up and the remaining steps are NaN)."""
     for t, name in ((wrec, "wrec"), (gx, "gx"), (hfull, "hfull")):
         _dev(t, name, "lstm_recurrence")
-    T, G, BP = gx.shape
-    H = G // 4
-    if G != 4 * H or tuple(wrec.shape) != (G, H) or tuple(hfull.shape) != (T + 1, H, BP):
-        raise ValueError("unetmi::lstm_recurrence: wrec [4H,H], gx [T,4H,BP], hfull [T+1,H,BP] expected")
+    if channel_major:
+        G, Tp, BP = gx.shape
+        T, H = Tp - 1, G // 4
+        ok = tuple(hfull.shape) == (H, Tp, BP) and xcd
+    else:
+        T, G, BP = gx.shape
+        H = G // 4
+        ok = tuple(hfull.shape) == (T + 1, H, BP)
+    if not ok or G != 4 * H or tuple(wrec.shape) != (G, H):
+        raise ValueError("unetmi::lstm_recurrence: wrec [4H,H] with gx [T,4H,BP], hfull [T+1,H,BP], or (XCD kernel) "
+                         "gx [4H,T+1,BP], hfull [H,T+1,BP] expected")
     key = (gx.device, bool(xcd))
     with torch.cuda.device(gx.device):
         stream = _stream(gx)
@@ -530,8 +538,8 @@ def _lstm_recurrence_cuda(wrec, gx, hfull, xcd):
             ws = _lstm_scratch.get(key)
             if ws is None:
                 ws = _lstm_scratch[key] = torch.empty(nbytes // 4, dtype=torch.int32, device=gx.device)
-            check(_lib.lib.unetmi_lstm_recurrence_xcd(T, BP, H, _ptr(wrec), _ptr(gx), _ptr(hfull), _ptr(ws), nbytes,
-                                                      stream), "unetmi_lstm_recurrence_xcd")
+            check(_lib.lib.unetmi_lstm_recurrence_xcd(T, BP, H, _ptr(wrec), _ptr(gx), _ptr(hfull), int(channel_major),
+                                                      _ptr(ws), nbytes, stream), "unetmi_lstm_recurrence_xcd")
             return ws[8].clone()
         sync = _lstm_scratch.get(key)
         if sync is None or sync.numel() != H // 4 + 1:
@@ -678,7 +686,7 @@ def _(src, map):
 
 
 @torch.library.register_fake("unetmi::lstm_recurrence")
-def _(wrec, gx, hfull, xcd):
+def _(wrec, gx, hfull, xcd, channel_major):
     return gx.new_empty((), dtype=torch.int32)
 
 
