@@ -218,6 +218,16 @@ int unetmi_layernorm_f_fwd(int N, int C, int F, int T, int C_out, int c_off, flo
 int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const void* y, const void* x, void* out,
                          int dtype, void* stream);
 
+/* InstanceNorm2d + activation of an Encoder / Decoder built with norm="InstanceNorm2d" (UNet_m.py:312-345,
+ * DSUNet.py:62-93 with type_norm="InstanceNorm2d"): out = gate[n,c] * act(gamma[c] * (z - mean[n,c]) * rstd[n,c]
+ * + beta[c]) with the statistics of each (n, c) plane over its HW values (biased variance, eps inside the root),
+ * which nn.InstanceNorm2d uses in train() and eval() alike unless it tracks running statistics.  gamma / beta /
+ * gate may be null (InstanceNorm2d's default has no affine parameters); act_param: the slope of LeakyReLU / PReLU,
+ * one value or one per channel.  One launch, the plane is streamed twice. */
+int unetmi_instnorm_act_fwd(int N, int C, int HW, const void* z, const float* gamma, const float* beta, float eps, int act,
+                            const float* act_param, int act_param_per_channel, const float* gate, void* out, int dtype,
+                            void* stream);
+
 /* Gate stage of DSUNet's gated convolutions (GConv / TrGConv, DSUNet.py:134-172, :241-275), which compute
  * sigmoid(conv_m(x)) * conv_c(x) [-> norm -> activation].  The two convolutions share geometry and input, so
  * they run as ONE unetmi_conv2d_fwd launch with the weights stacked to 2K output channels (features first,

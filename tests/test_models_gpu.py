@@ -678,3 +678,47 @@ def test_dsunet_se_residual_is_refused(device):
     import unet_amd
     with pytest.raises(Exception):
         unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8), type_residual="SE")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [("LeakyReLU", False, False), ("PReLU", True, True), ("SiLU", False, True), ("GELU", True, False)])
+def test_instance_norm_blocks_one_launch(device, case, dtype):
+    """Encoder / Decoder built with norm="InstanceNorm2d" (UNet_m.py:312-345): the HIP convolution, then InstanceNorm2d
+    + activation (+ gate) as one launch, against the torch CPU modules; a mean far from zero, affine on and off."""
+    import torch.nn as nn
+    import unet_amd
+    from unet_amd import ops
+    from unet_amd.fused import instance_norm_act
+    act_name, affine, with_gate = case
+    g = torch.Generator().manual_seed(17)
+    z = (torch.randn(3, 10, 33, 45, generator=g) * 1.7 + 23.0).to(dtype)
+    norm = nn.InstanceNorm2d(10, affine=affine)
+    act = {"LeakyReLU": nn.LeakyReLU(0.1), "PReLU": nn.PReLU(10), "SiLU": nn.SiLU(), "GELU": nn.GELU()}[act_name]
+    with torch.no_grad():
+        if affine:
+            norm.weight.copy_(torch.rand(10, generator=g) + 0.5)
+            norm.bias.copy_(torch.randn(10, generator=g) * 0.2)
+        if act_name == "PReLU":
+            act.weight.copy_(torch.linspace(-0.2, 0.5, 10))
+        gate = torch.rand(3, 10, generator=g) if with_gate else None
+        want = act(norm(z.float()))
+        if gate is not None:
+            want = want * gate[:, :, None, None]
+    got = instance_norm_act(z.to(device), norm.to(device), act.to(device), None if gate is None else gate.to(device))
+    assert got is not None and got.dtype == dtype
+    assert_close(got.float(), want, tol=1e-4 if dtype == torch.float32 else 6e-3, what="InstanceNorm2d + " + act_name)
+    norm.cpu(), act.cpu()
+    if dtype == torch.float32 and not with_gate:
+        # the whole block, through the reference's constructor
+        ref_conv = nn.Conv2d(6, 10, (5, 3), (2, 1), (2, 1))
+        dev = unet_amd.Encoder(6, 10, (5, 3), (2, 1), (2, 1), norm="InstanceNorm2d", activation="LeakyReLU").eval()
+        with torch.no_grad():
+            ref_conv.weight.copy_(dev.conv.weight)
+            ref_conv.bias.copy_(dev.conv.bias)
+            x = torch.randn(2, 6, 31, 40, generator=g)
+            want = nn.functional.leaky_relu(nn.functional.instance_norm(ref_conv(x)), 0.01)
+            got = dev.to(device)(x.to(device))
+        assert_close(got, want, what="Encoder(norm='InstanceNorm2d')")
+    # an InstanceNorm2d that normalises with tracked running statistics in eval mode is not this kernel's case
+    tracked = nn.InstanceNorm2d(10, track_running_stats=True).eval()
+    assert instance_norm_act(z.to(device).float(), tracked.to(device), nn.ReLU(), None) is None

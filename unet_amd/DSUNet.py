@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .fused import FusedConv, activation_code, require_device_tensor
+from .fused import FusedConv, activation_code, instance_norm_act, require_device_tensor
 from .ops import glu
 
 
@@ -40,7 +40,11 @@ class _Block(nn.Module):
             object.__setattr__(self, "_fused", FusedConv(conv, self.bn, self.relu))
         if self._fused.fusable():
             return self._fused(x, skip, gate=gate)
-        y = self.relu(self.bn(self._fused(x, skip, epilogue=False)))
+        z = self._fused(x, skip, epilogue=False)
+        y = instance_norm_act(z, self.bn, self.relu, gate)             # InstanceNorm2d + activation + gate: one launch
+        if y is not None:
+            return y
+        y = self.relu(self.bn(z))
         return y if gate is None else y * gate[:, :, None, None]
 
 

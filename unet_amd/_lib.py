@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "unetmi_lstm_recurrence_xcd_workspace_bytes",
     "unetmi_lstm_recurrence_xcd",
     "unetmi_glu_fwd",
+    "unetmi_instnorm_act_fwd",
     "unetmi_conv2d_b16_packed_weight_bytes",
     "unetmi_conv2d_b16_pack_weights",
     "unetmi_conv2d_b16_fwd",
@@ -119,6 +120,8 @@ def _load():
     lib.unetmi_lstm_recurrence_xcd.restype = ctypes.c_int
     lib.unetmi_glu_fwd.argtypes = [ci] * 3 + [fp] * 3 + [ci] + [fp] * 3 + [ci, vp]
     lib.unetmi_glu_fwd.restype = ctypes.c_int
+    lib.unetmi_instnorm_act_fwd.argtypes = [ci] * 3 + [fp] * 3 + [cf, ci, fp, ci, fp, fp, ci, vp]
+    lib.unetmi_instnorm_act_fwd.restype = ctypes.c_int
     lib.unetmi_adam_step.argtypes = [sz] + [fp] * 4 + [cf] * 6 + [ci, vp]
     lib.unetmi_conv2d_b16_packed_weight_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.unetmi_conv2d_b16_packed_weight_bytes.restype = sz

@@ -115,6 +115,57 @@ __global__ __launch_bounds__(256) void layernorm_f_strip_kernel(const void* __re
             buf_st_act<BF16>((v[i] - mean) * rstd * gamma[f0 + i] + beta[f0 + i], rs_out, voff, (f0 + i) * T * EB);
 }
 
+// InstanceNorm2d (per (n, c) plane over H x W, biased variance; optional per-channel affine) followed by the block's
+// activation, and optionally a per-(n, c) gate, in one launch: one workgroup per plane, the statistics pass
+// (deviations from the plane's first value, so a large mean does not cancel) and the normalising pass both
+// stream the plane, which is at most a few hundred KB and stays in L2 between them.
+__device__ __forceinline__ float in_act(int act, float u, float p) {
+    switch (act) {
+        case UNETMI_ACT_LEAKY: return u >= 0.f ? u : p * u;
+        case UNETMI_ACT_RELU: return fmaxf(u, 0.f);
+        case UNETMI_ACT_SILU: return u / (1.f + expf(-u));
+        case UNETMI_ACT_SOFTPLUS: return u > 20.f ? u : log1pf(expf(u));
+        case UNETMI_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
+        case UNETMI_ACT_TANH: return tanhf(u);
+        case UNETMI_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+        default: return u;
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void instnorm_act_kernel(const void* __restrict__ z, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ act_param,
+                                                           int act_pc, const float* __restrict__ gate,
+                                                           void* __restrict__ out, int C, int HW, float eps, int act) {
+    __shared__ double s_red[2][4];
+    const int nc = blockIdx.x, c = nc % C;
+    const size_t base = (size_t)nc * HW;
+    const float x0 = ld_act<BF16>(z, base);
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float d = ld_act<BF16>(z, base + i) - x0;
+        s0 += d;
+        s1 = fmaf(d, d, s1);
+    }
+    double d0 = s0, d1 = s1;
+    for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_down(d0, o, 64); d1 += __shfl_down(d1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = d0; s_red[1][threadIdx.x >> 6] = d1; }
+    __syncthreads();
+    const double t0 = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    const double t1 = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    const double md = t0 / HW;
+    double var = t1 / HW - md * md;
+    if (var < 0.0) var = 0.0;
+    const float mean = x0 + (float)md;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = (gamma ? gamma[c] : 1.f) * rstd;
+    const float b = (beta ? beta[c] : 0.f) - mean * g;
+    const float ap = act_param ? act_param[act_pc ? c : 0] : 0.f;
+    const float gt = gate ? gate[nc] : 1.f;
+    for (int i = threadIdx.x; i < HW; i += 256)
+        st_act<BF16>(out, base + i, in_act(act, fmaf(ld_act<BF16>(z, base + i), g, b), ap) * gt);
+}
+
 // out[n,k,f,t] = (tanh(y[n,k,f,t]) + eps) * x[n,k,f,t], x having Cx >= K channels (first K used)
 template <bool BF16>
 __global__ __launch_bounds__(256) void tanh_mask_kernel(const void* __restrict__ y, const void* __restrict__ x,
@@ -249,6 +300,27 @@ int unetmi_layernorm_f_fwd(int N, int C, int F, int T, int C_out, int c_off, flo
                            x, gamma, beta, out, C, F, T, C_out, c_off, eps);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("layernorm launch: ") + hipGetErrorString(e));
+}
+
+int unetmi_instnorm_act_fwd(int N, int C, int HW, const void* z, const float* gamma, const float* beta, float eps, int act,
+                            const float* act_param, int act_param_per_channel, const float* gate, void* out, int dtype,
+                            void* stream) {
+    if (N < 0 || C < 1 || HW < 1) return api_fail(UNETMI_E_BAD_DESC, "instnorm_act: bad sizes");
+    if (act < UNETMI_ACT_NONE || act > UNETMI_ACT_GELU) return api_fail(UNETMI_E_BAD_DESC, "instnorm_act: unknown activation");
+    if (N == 0) return UNETMI_OK;
+    if (!z || !out) return api_fail(UNETMI_E_BAD_ARG, "instnorm_act: null tensor pointer");
+    if (act == UNETMI_ACT_LEAKY && !act_param) return api_fail(UNETMI_E_BAD_ARG, "instnorm_act: LeakyReLU / PReLU needs its slope");
+    if ((long long)N * C > 0x7fffffffll) return api_fail(UNETMI_E_UNSUPPORTED, "instnorm_act: too many planes");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == UNETMI_DTYPE_BF16)
+        hipLaunchKernelGGL(instnorm_act_kernel<true>, dim3(N * C), dim3(256), 0, s, z, gamma, beta, act_param,
+                           act_param_per_channel, gate, out, C, HW, eps, act);
+    else if (dtype == UNETMI_DTYPE_F32)
+        hipLaunchKernelGGL(instnorm_act_kernel<false>, dim3(N * C), dim3(256), 0, s, z, gamma, beta, act_param,
+                           act_param_per_channel, gate, out, C, HW, eps, act);
+    else return api_fail(UNETMI_E_BAD_DESC, "instnorm_act: unknown dtype");
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("instnorm_act launch: ") + hipGetErrorString(e));
 }
 
 int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const void* y, const void* x, void* out,

@@ -47,6 +47,27 @@ def activation_code(act):
     return None
 
 
+def instance_norm_act(z, norm, act, gate=None):
+    """act(norm(z)) [* gate] for an nn.InstanceNorm2d that normalises with each plane's own statistics (its default:
+    no running statistics) as ONE launch (unetmi_instnorm_act_fwd), or None when norm / act are not such a pair."""
+    if not isinstance(norm, nn.InstanceNorm2d) or (norm.track_running_stats and not norm.training):
+        return None
+    found = activation_code(act)
+    if found is None or z.dim() != 4 or not z.is_contiguous():
+        return None
+    code, par = found
+    if isinstance(par, torch.Tensor):
+        ap = par.detach().float().reshape(-1).contiguous()
+    elif par is not None:
+        ap = torch.full((1,), float(par), dtype=torch.float32, device=z.device)
+    else:
+        ap = None
+    from .ops import instnorm_act
+    gamma = norm.weight.detach().float().contiguous() if norm.weight is not None else None
+    beta = norm.bias.detach().float().contiguous() if norm.bias is not None else None
+    return instnorm_act(z, gamma, beta, norm.eps, code, ap, None if gate is None else gate.float().contiguous())
+
+
 def require_device_tensor(x, who):
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
         raise RuntimeError(

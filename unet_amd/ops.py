@@ -162,6 +162,7 @@ _LIBRARY.define("layernorm_f(Tensor x, Tensor gamma, Tensor beta, float eps, Ten
 _LIBRARY.define("tanh_mask_mul(Tensor y, Tensor x, float eps) -> Tensor")
 _LIBRARY.define("crf_apply(Tensor H, Tensor X) -> Tensor")
 _LIBRARY.define("glu(Tensor z, Tensor? scale, Tensor? shift, int act, Tensor? act_param, Tensor? gate) -> Tensor")
+_LIBRARY.define("instnorm_act(Tensor z, Tensor? gamma, Tensor? beta, float eps, int act, Tensor? act_param, Tensor? gate) -> Tensor")
 _LIBRARY.define("pwconv64(Tensor x, Tensor? x2, Tensor weight, Tensor? bias, Tensor scale, Tensor shift, Tensor? slope, "
                 "bool act_first, bool residual) -> Tensor")
 _LIBRARY.define("resblock_layer(Tensor x, Tensor? x2, Tensor dw_weight, Tensor? dw_bias, Tensor pw_weight, "
@@ -297,6 +298,30 @@ def _glu_cuda(z, scale, shift, act, act_param, gate):
     return out
 
 
+def _instnorm_act_cuda(z, gamma, beta, eps, act, act_param, gate):
+    code = dtype_code(z)
+    _dev(z, "z", "instnorm_act", z.dtype)
+    N, C = z.shape[0], z.shape[1]
+    HW = z.numel() // max(N * C, 1)
+    for t, name, numel in ((gamma, "gamma", C), (beta, "beta", C), (gate, "gate", N * C)):
+        if t is not None:
+            _dev(t, name, "instnorm_act")
+            if t.numel() != numel:
+                raise ValueError("unetmi::instnorm_act: {} has {} elements, expected {}".format(name, t.numel(), numel))
+    act_pc = 0
+    if act_param is not None:
+        _dev(act_param, "act_param", "instnorm_act")
+        if act_param.numel() not in (1, C):
+            raise ValueError("unetmi::instnorm_act: act_param needs 1 or {} elements".format(C))
+        act_pc = int(act_param.numel() > 1)
+    out = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        check(_lib.lib.unetmi_instnorm_act_fwd(N, C, HW, _ptr(z), _ptr(gamma), _ptr(beta), eps, act, _ptr(act_param), act_pc,
+                                               _ptr(gate), _ptr(out), code, _stream(z)), "unetmi_instnorm_act_fwd")
+    return out
+
+
+_LIBRARY.impl("instnorm_act", _instnorm_act_cuda, "CUDA")
 _LIBRARY.impl("glu", _glu_cuda, "CUDA")
 _LIBRARY.impl("pwconv64", _pwconv64_cuda, "CUDA")
 _LIBRARY.impl("dwconv2d_fwd", _dwconv2d_fwd_cuda, "CUDA")
@@ -308,6 +333,11 @@ _LIBRARY.impl("crf_apply", _crf_apply_cuda, "CUDA")
 @torch.library.register_fake("unetmi::dwconv2d_fwd")
 def _(x, x2, weight, bias, padding, dilation):
     return torch.empty_like(x)
+
+
+@torch.library.register_fake("unetmi::instnorm_act")
+def _(z, gamma, beta, eps, act, act_param, gate):
+    return torch.empty_like(z)
 
 
 @torch.library.register_fake("unetmi::glu")
@@ -342,6 +372,7 @@ crf_apply = torch.ops.unetmi.crf_apply
 resblock_layer = torch.ops.unetmi.resblock_layer
 pwconv64 = torch.ops.unetmi.pwconv64
 glu = torch.ops.unetmi.glu
+instnorm_act = torch.ops.unetmi.instnorm_act
 
 
 # ---------------------------------------------------------------------------------------
