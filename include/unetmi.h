@@ -179,9 +179,11 @@ int unetmi_pwconv64_fwd(int N, int H, int W, const void* x, const void* x2, cons
  *   gx[t][g*H+u][b]  = (W_ih x_t + b_ih + b_hh)[g*H+u]  for all t     (gate order i, f, g, o)
  *   wrec[4H][H]      = W_hh W_hr                                       (recurrent and projection matrix folded)
  * and reads the pre-projection states back:  hfull[t+1][u][b] = o_t * tanh(c_t);  h_t = W_hr hfull[t+1].
- * hfull is [T+1][H][BP] with slot 0 = the initial state (zeros for the reference's call); BP = batch padded to
- * a multiple of 16 (<= 64; padded columns compute on zeros and are ignored).  sync_ws: 4 * (H/4 + 1) bytes of
- * device scratch (cleared by the call).  H must be 640.  All workgroups have to be resident at once (checked with
+ * hfull is [T+1][HP][BP], HP = H rounded up to a multiple of 16, with slot 0 = the initial state (zeros for the
+ * reference's call) and rows H..HP-1 of every slot zero (the caller clears the buffer once; the kernel never
+ * writes them); BP = batch padded to a multiple of 16 (<= 64; padded columns compute on zeros and are ignored).
+ * sync_ws: 4 * (H/4 + 1) bytes of device scratch (cleared by the call).  H must be 640 (ResUNet.py:139) or 300
+ * (ResUNet.py:335, UNet_m.py:587-610).  All workgroups have to be resident at once (checked with
  * the runtime's occupancy query); the call refuses otherwise.  If the device-wide barrier inside ever times out
  * (a workgroup that is not resident after all, e.g. the GPU is shared), every slot of hfull from the step that
  * timed out on is filled with NaN and the last word of sync_ws, ((uint32_t*)sync_ws)[H/4], is left non-zero

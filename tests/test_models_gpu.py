@@ -722,3 +722,27 @@ def test_instance_norm_blocks_one_launch(device, case, dtype):
     # an InstanceNorm2d that normalises with tracked running statistics in eval mode is not this kernel's case
     tracked = nn.InstanceNorm2d(10, track_running_stats=True).eval()
     assert instance_norm_act(z.to(device).float(), tracked.to(device), nn.ReLU(), None) is None
+
+
+@pytest.mark.parametrize("shape", [(192, 300, 192, 3), (210, 300, 210, 3)])
+@pytest.mark.parametrize("B,T", [(2, 33), (32, 12), (70, 5)])
+def test_projected_lstm_hidden_300(device, shape, B, T):
+    """The projected LSTMs of ResUNetOnFreq (ResUNet.py:335: LSTM(192, 300, 3, proj 192)) and of LSTMBlock
+    (UNet_m.py:587-610: LSTM(210, 300, 3, proj 210)) on the device-wide-barrier recurrence kernel -- hidden size 300
+    is padded to 304 rows per state slot -- against torch's CPU LSTM."""
+    import copy
+    import unet_amd
+    from unet_amd.lstm import lstm_forward, supported
+    from unet_amd.seeding import normal
+    n_in, hidden, proj, layers = shape
+    ref = torch.nn.LSTM(n_in, hidden, layers, batch_first=True, proj_size=proj)
+    holder = torch.nn.Module()
+    holder.lstm = ref
+    unet_amd.seeded_fill_(holder, seed=73)
+    assert supported(ref)
+    x = normal("lstm300/x", (B, T, n_in), seed=73)
+    with torch.no_grad():
+        want = ref(x)[0]
+    got = lstm_forward(copy.deepcopy(ref).to(device), x.to(device), {})
+    assert not torch.isnan(got).any(), "the recurrence kernel aborted"
+    assert_close(got, want, tol=2e-5, what="projected LSTM, hidden 300")

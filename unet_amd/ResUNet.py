@@ -156,8 +156,8 @@ class ResUNetOnFreq(nn.Module):
 
     Same launches as ``ResUNet`` with one input branch; the 30-channel ResBlocks take the
     depthwise + pointwise launches (the one-launch-per-layer kernel is the 64-channel one) and
-    ``nn.LSTM(192, 300, 3, proj_size=192)`` is not the shape the recurrence kernel holds, so it
-    runs torch's device LSTM.  The mask activation is fused into the output layer when the
+    ``nn.LSTM(192, 300, 3, proj_size=192)`` runs on the device-wide-barrier recurrence kernel (hidden size 300
+    padded to 304 rows per state slot).  The mask activation is fused into the output layer when the
     epilogue has it (Sigmoid, Softplus at threshold 20); another threshold runs the module.
     """
 
@@ -232,19 +232,24 @@ class ResUNetOnFreq(nn.Module):
 
 
 class LSTMBlock(nn.Module):
-    """[B,C,F',T] -> [B,T,C*F'] -> projected LSTM -> back (UNet_m.py:587-610); torch's device LSTM."""
+    """[B,C,F',T] -> [B,T,C*F'] -> projected LSTM -> back (UNet_m.py:587-610): the recurrence kernel for hidden
+    sizes 300 and 640, torch's device LSTM otherwise."""
 
     def __init__(self, n_dim, n_hidden, n_layer=3, proj_size=None, dropout=0.2):
         super().__init__()
         if proj_size is None:
             proj_size = n_dim
         self.rnn = nn.LSTM(n_dim, n_hidden, n_layer, batch_first=True, proj_size=proj_size, dropout=dropout)
+        self._lstm_cache = {}
 
     def forward(self, x):
         require_device_tensor(x, "LSTMBlock")
         B, C, F, T = x.shape
         seq = x.reshape(B, C * F, T).permute(0, 2, 1)
-        y = self.rnn(seq.float())[0].to(x.dtype)
+        if lstm_supported(self.rnn):             # hidden size 300 / 640: one persistent recurrence launch per layer
+            y = lstm_forward(self.rnn, seq.float().contiguous(), self._lstm_cache).to(x.dtype)
+        else:
+            y = self.rnn(seq.float())[0].to(x.dtype)
         return y.permute(0, 2, 1).reshape(B, C, F, T).contiguous()
 
 

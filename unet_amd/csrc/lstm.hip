@@ -27,16 +27,17 @@ int api_fail(int code, const std::string& msg);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kLstmH = 640;              // hidden size the kernel is built for
-constexpr int kLstmKS = kLstmH / 16;     // 16x16x4 k-steps per wave (K split over 4 waves)
+// The kernel is instantiated per PADDED hidden size HP (a multiple of 16: the K range is split over 4 waves in
+// 16x16x4 steps): 640 for ResUNet's bottleneck, 304 for the hidden size 300 of ResUNetOnFreq / LSTMBlock
+// (ResUNet.py:335, UNet_m.py:587-610).  A state slot has HP rows; rows H..HP-1 stay zero and meet zero weights.
 constexpr unsigned kSpinLimit = 1u << 21;
 
 struct LstmArgs {
     const float* wrec;     // [4H][H] folded recurrent matrix, row g*H + u
     const float* gx;       // [T][4H][BP] input contribution incl. both biases
-    float* hfull;          // [T+1][H][BP]; slot 0 = initial state, step t reads slot t and writes slot t+1
+    float* hfull;          // [T+1][HP][BP]; slot 0 = initial state, step t reads slot t and writes slot t+1
     unsigned* sync;        // [nwg] step each workgroup has finished, then [1] abort flag
-    int T, BP, nwg;
+    int T, BP, nwg, H;     // H: the real hidden size (gx and wrec rows are g*H + u)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -78,10 +79,11 @@ __device__ __forceinline__ bool grid_barrier(unsigned* flags, int nwg, unsigned 
     return *s_flag != 0;
 }
 
-template <int NCT>      // 16-column batch tiles: BP = 16 * NCT
+template <int NCT, int kLstmH>      // 16-column batch tiles: BP = 16 * NCT; padded hidden size
 __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs a) {
     constexpr int BP = 16 * NCT;
-    __shared__ float s_a[kLstmH / 4 * 64];            // [k-step][lane] A operands: 16 rows x 640
+    constexpr int kLstmKS = kLstmH / 16;              // 16x16x4 k-steps per wave (K split over 4 waves)
+    __shared__ float s_a[kLstmH / 4 * 64];            // [k-step][lane] A operands: 16 rows x HP
     __shared__ float s_p[4][16][BP + 1];              // per-wave partial gate sums
     __shared__ int s_flag;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -90,8 +92,8 @@ __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs 
 
     // A operand of k-step ks, lane l: Wrec[row(l&15)][4*ks + (l>>4)], row r = gate (r>>2), unit u0 + (r&3)
     for (int i = tid; i < kLstmH / 4 * 64; i += 256) {
-        const int l = i & 63, ks = i >> 6, r = l & 15;
-        s_a[i] = a.wrec[(size_t)((r >> 2) * kLstmH + u0 + (r & 3)) * kLstmH + 4 * ks + (l >> 4)];
+        const int l = i & 63, ks = i >> 6, r = l & 15, k = 4 * ks + (l >> 4);
+        s_a[i] = k < a.H ? a.wrec[(size_t)((r >> 2) * a.H + u0 + (r & 3)) * a.H + k] : 0.f;
     }
     // cell-update thread: unit u0 + cu, batch column cb
     const int cu = tid / BP, cb = tid - cu * BP;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs 
         if (cell_thread) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                gxv[g] = a.gx[((size_t)t * 4 * kLstmH + g * kLstmH + u0 + cu) * BP + cb];
+                gxv[g] = a.gx[((size_t)t * 4 * a.H + g * a.H + u0 + cu) * BP + cb];
         }
 #pragma unroll
         for (int ks = 0; ks < kLstmKS; ++ks) {
@@ -152,6 +154,33 @@ __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs 
             a.hfull[((size_t)tt * kLstmH + u0 + cu) * BP + cb] = __builtin_nanf("");
 }
 
+template <int HP>
+static int launch_lstm(const LstmArgs& a, int cus, hipStream_t s) {
+    // the device-wide barrier needs every workgroup resident at once: ask the runtime how many workgroups of this
+    // kernel (its registers and LDS) one compute unit holds, instead of assuming one
+    int per_cu = 0;
+    hipError_t oe;
+    switch (a.BP / 16) {
+        case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<1, HP>, 256, 0); break;
+        case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<2, HP>, 256, 0); break;
+        case 3: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<3, HP>, 256, 0); break;
+        default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<4, HP>, 256, 0); break;
+    }
+    if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence occupancy query: ") + hipGetErrorString(oe));
+    if ((long long)per_cu * cus < a.nwg)
+        return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: the device cannot hold all workgroups at once");
+    hipError_t e = hipMemsetAsync(a.sync, 0, (size_t)(a.nwg + 1) * sizeof(unsigned), s);
+    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence memset: ") + hipGetErrorString(e));
+    switch (a.BP / 16) {
+        case 1: hipLaunchKernelGGL((lstm_recurrence_kernel<1, HP>), dim3(a.nwg), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((lstm_recurrence_kernel<2, HP>), dim3(a.nwg), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((lstm_recurrence_kernel<3, HP>), dim3(a.nwg), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((lstm_recurrence_kernel<4, HP>), dim3(a.nwg), dim3(256), 0, s, a); break;
+    }
+    e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_recurrence launch: ") + hipGetErrorString(e));
+}
+
 }  // namespace unetmi
 
 using namespace unetmi;
@@ -159,7 +188,7 @@ using namespace unetmi;
 extern "C" int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float* gx, float* hfull,
                                       void* sync_ws, void* stream) {
     if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence: bad sizes");
-    if (H != kLstmH) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: built for hidden size 640");
+    if (H != 640 && H != 300) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: built for hidden sizes 640 and 300");
     if (BP % 16 != 0 || BP > 64) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: padded batch must be 16, 32, 48 or 64");
     if (T == 0) return UNETMI_OK;
     if (!wrec || !gx || !hfull || !sync_ws) return api_fail(UNETMI_E_BAD_ARG, "lstm_recurrence: null pointer");
@@ -168,29 +197,7 @@ extern "C" int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, c
         return api_fail(UNETMI_E_HIP, "lstm_recurrence: cannot query the device");
     LstmArgs a{};
     a.wrec = wrec; a.gx = gx; a.hfull = hfull; a.sync = static_cast<unsigned*>(sync_ws);
-    a.T = T; a.BP = BP; a.nwg = H / 4;
-    // the device-wide barrier needs every workgroup resident at once: ask the runtime how many workgroups of this
-    // kernel (its registers and LDS) one compute unit holds, instead of assuming one
-    int per_cu = 0;
-    hipError_t oe;
-    switch (BP / 16) {
-        case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<1>, 256, 0); break;
-        case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<2>, 256, 0); break;
-        case 3: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<3>, 256, 0); break;
-        default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_recurrence_kernel<4>, 256, 0); break;
-    }
-    if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence occupancy query: ") + hipGetErrorString(oe));
-    if ((long long)per_cu * cus < a.nwg)
-        return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence: the device cannot hold all workgroups at once");
+    a.T = T; a.BP = BP; a.nwg = H / 4; a.H = H;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(sync_ws, 0, (size_t)(a.nwg + 1) * sizeof(unsigned), s);
-    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence memset: ") + hipGetErrorString(e));
-    switch (BP / 16) {
-        case 1: hipLaunchKernelGGL(lstm_recurrence_kernel<1>, dim3(a.nwg), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(lstm_recurrence_kernel<2>, dim3(a.nwg), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(lstm_recurrence_kernel<3>, dim3(a.nwg), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(lstm_recurrence_kernel<4>, dim3(a.nwg), dim3(256), 0, s, a); break;
-    }
-    e = hipGetLastError();
-    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_recurrence launch: ") + hipGetErrorString(e));
+    return H == 640 ? launch_lstm<640>(a, cus, s) : launch_lstm<304>(a, cus, s);
 }

@@ -23,7 +23,7 @@ KERNEL = "xcd"
 
 
 def supported(lstm):
-    return (isinstance(lstm, nn.LSTM) and lstm.hidden_size == 640 and lstm.proj_size > 0 and lstm.batch_first
+    return (isinstance(lstm, nn.LSTM) and lstm.hidden_size in (640, 300) and lstm.proj_size > 0 and lstm.batch_first
             and not lstm.bidirectional and lstm.bias and (lstm.dropout == 0.0 or not lstm.training))
 
 
@@ -40,8 +40,8 @@ def _folded_recurrent_matrix(lstm, layer, cache):
     return hit[1]
 
 
-def _xcd_kernel_fits(dev):
-    return KERNEL == "xcd" and torch.cuda.get_device_properties(dev).multi_processor_count == 256
+def _xcd_kernel_fits(dev, hidden):
+    return KERNEL == "xcd" and hidden == 640 and torch.cuda.get_device_properties(dev).multi_processor_count == 256
 
 
 def _recurrence(wrec, gx, hfull, use_xcd, channel_major=False):
@@ -107,11 +107,11 @@ def _forward_channel_major(lstm, x, cache):
 def lstm_forward(lstm, x, cache):
     """x [B, T, input] -> [B, T, proj]; zero initial state, inference only."""
     if not supported(lstm):
-        raise NotImplementedError("lstm_forward: built for batch_first projected LSTMs with hidden size 640")
+        raise NotImplementedError("lstm_forward: built for batch_first projected LSTMs with hidden size 640 or 300")
     if not x.is_cuda or x.dtype != torch.float32:
         raise ValueError("lstm_forward: x must be an fp32 device tensor")
     B, T, _ = x.shape
-    use_xcd = _xcd_kernel_fits(x.device)
+    use_xcd = _xcd_kernel_fits(x.device, lstm.hidden_size)
     group = XCD_BATCH_PER_LAUNCH if use_xcd else MAX_BATCH_PER_LAUNCH
     if B > group:                                   # sequences are independent: run them in groups
         return torch.cat([lstm_forward(lstm, x[i:i + group], cache) for i in range(0, B, group)], dim=0)
@@ -131,11 +131,15 @@ def lstm_forward(lstm, x, cache):
             bias = (getattr(lstm, "bias_ih_l{}".format(layer)).float() + getattr(lstm, "bias_hh_l{}".format(layer)).float()).detach()
             gx = torch.matmul(w_ih, seq) + bias[None, :, None]                        # [T, 4H, BP]
             wrec = _folded_recurrent_matrix(lstm, layer, cache)
-            hfull = torch.empty((T + 1, H, BP), dtype=torch.float32, device=dev)
-            hfull[0].zero_()
+            HP = (H + 15) // 16 * 16                     # the barrier kernel's slots are padded to 16 rows (zeros)
+            if HP == H:
+                hfull = torch.empty((T + 1, H, BP), dtype=torch.float32, device=dev)
+                hfull[0].zero_()
+            else:
+                hfull = torch.zeros((T + 1, HP, BP), dtype=torch.float32, device=dev)
             status = _recurrence(wrec, gx, hfull, use_xcd)
             aborted = aborted | status                                                # the kernel's status word, kept on the device
-            seq = torch.matmul(w_hr, hfull[1:])                                       # [T, proj, BP] = next layer's input
+            seq = torch.matmul(w_hr, hfull[1:, :H])                                   # [T, proj, BP] = next layer's input
         out = seq[:, :, :B].permute(2, 0, 1).contiguous()
         # a recurrence that gave up waiting (GPU shared with other work) must not pass for a result: the whole
         # output becomes NaN, without a host round trip

@@ -545,7 +545,8 @@ _lstm_scratch = {}
 
 def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major):
     """One layer's T dependent steps with the folded recurrent matrix wrec [4H, H].  Step-major: gx [T, 4H, BP]
-    (input contributions + bias), hfull [T+1, H, BP] (slot 0 = initial state, slots 1.. are filled).  Channel-major
+    (input contributions + bias), hfull [T+1, HP, BP], HP = H rounded up to 16 (slot 0 = initial state, slots 1..
+    are filled; rows H..HP-1 must be zero).  Channel-major
     (XCD kernel only): gx [4H, T+1, BP] with slot t+1 = step t, hfull [H, T+1, BP].  Returns the kernel's status
     word as a device scalar (non-zero: a wait gave up and the remaining steps are NaN)."""
     for t, name in ((wrec, "wrec"), (gx, "gx"), (hfull, "hfull")):
@@ -557,11 +558,11 @@ def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major):
     else:
         T, G, BP = gx.shape
         H = G // 4
-        ok = tuple(hfull.shape) == (T + 1, H, BP)
+        ok = tuple(hfull.shape) == (T + 1, (H + 15) // 16 * 16, BP)       # a slot's rows are padded to a multiple of 16
     if not ok or G != 4 * H or tuple(wrec.shape) != (G, H):
         raise ValueError("unetmi::lstm_recurrence: wrec [4H,H] with gx [T,4H,BP], hfull [T+1,H,BP], or (XCD kernel) "
                          "gx [4H,T+1,BP], hfull [H,T+1,BP] expected")
-    key = (gx.device, bool(xcd))
+    key = (gx.device, bool(xcd), H)
     with torch.cuda.device(gx.device):
         stream = _stream(gx)
         if xcd:
