@@ -310,6 +310,8 @@ def test_every_entry_point_is_a_dispatcher_op_with_shape_inference():
         assert ops.conv2d_wgrad(z, None, torch.empty(2, 4, 5, 7), geom, [1, 0]).shape == (8, 4, 3, 3)
         status = ops.lstm_recurrence(torch.empty(2560, 640), torch.empty(5, 2560, 16), torch.empty(6, 640, 16), True, False)
         assert status.shape == () and status.dtype == torch.int32
+        status = ops.gru_recurrence(torch.empty(384, 128), torch.empty(384), torch.empty(5, 384, 16), torch.empty(6, 128, 16))
+        assert status.shape == () and status.dtype == torch.int32
         b = ops.blocked_from_nchw(z)
         assert b.shape == (2, 2, 5, 7, 8) and b.dtype == torch.bfloat16
         assert ops.nchw_from_blocked(b, 8, True).dtype == torch.float32

@@ -746,3 +746,28 @@ def test_projected_lstm_hidden_300(device, shape, B, T):
     got = lstm_forward(copy.deepcopy(ref).to(device), x.to(device), {})
     assert not torch.isnan(got).any(), "the recurrence kernel aborted"
     assert_close(got, want, tol=2e-5, what="projected LSTM, hidden 300")
+
+
+@pytest.mark.parametrize("n_in,hidden", [(128, 128), (256, 512), (256, 256)])
+@pytest.mark.parametrize("B,T,with_state", [(4, 33, False), (32, 12, True), (130, 7, True)])
+def test_gru_recurrence(device, n_in, hidden, B, T, with_state):
+    """The GRUs of the TGRU bottlenecks (DSUNet.py:290: GRU(128, 128); UDSS.py:48: GRU(256, 512)) and of cRNN
+    (UDSS.py:197-200: GRU(256, 256)) on the persistent recurrence kernel against torch's CPU GRU, with and without a
+    caller's initial state, at batches below, at and beyond one launch's 64 columns."""
+    import copy
+    import unet_amd
+    from unet_amd.gru import gru_forward, supported
+    from unet_amd.seeding import normal
+    ref = torch.nn.GRU(n_in, hidden, batch_first=True).eval()
+    holder = torch.nn.Module()
+    holder.gru = ref
+    unet_amd.seeded_fill_(holder, seed=79)
+    assert supported(ref)
+    x = normal("gru/x", (B, T, n_in), seed=79)
+    h0 = normal("gru/h0", (1, B, hidden), seed=79) * 0.5 if with_state else None
+    with torch.no_grad():
+        want, want_h = ref(x, h0)
+    got, got_h = gru_forward(copy.deepcopy(ref).to(device), x.to(device), None if h0 is None else h0.to(device))
+    assert not torch.isnan(got).any(), "the recurrence kernel aborted"
+    assert_close(got, want, tol=2e-5, what="GRU outputs")
+    assert_close(got_h, want_h, tol=2e-5, what="GRU final state")

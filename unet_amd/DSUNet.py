@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import gru as _gru
 from .fused import FusedConv, activation_code, instance_norm_act, require_device_tensor
 from .ops import glu
 
@@ -212,8 +213,8 @@ class TrGConv(_Gated):
 
 
 class TGRUBlock(nn.Module):
-    """GRU along time for every (batch, frequency) row (torch's device GRU), then 1x1 conv + BatchNorm +
-    ReLU as one fused launch (DSUNet.py:281-312)."""
+    """GRU along time for every (batch, frequency) row (one persistent recurrence launch, unet_amd.gru), then 1x1
+    conv + BatchNorm + ReLU as one fused launch (DSUNet.py:281-312)."""
 
     def __init__(self, in_channels, hidden_size, out_channels, skipGRU=False, **kwargs):
         super().__init__()
@@ -230,7 +231,7 @@ class TGRUBlock(nn.Module):
         require_device_tensor(x, "TGRUBlock")
         B, C, F, T = x.shape
         x_ = x.permute(0, 2, 3, 1).reshape(B * F, T, C)
-        y_, rnn_state = self.GRU(x_.float(), rnn_state)
+        y_, rnn_state = _gru.run(self.GRU, x_.float(), rnn_state)
         y2 = y_.reshape(B, F, T, self.hidden_size).permute(0, 3, 1, 2).contiguous().to(x.dtype)
         if self._fused is None:
             object.__setattr__(self, "_fused", FusedConv(self.conv, self.bn, self.relu))

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from .DSUNet import Attractor, AttractEncoder
+from . import gru as _gru
 from .fused import FusedConv, require_device_tensor
 
 
@@ -293,8 +294,8 @@ class Decoder(_ComplexBlock):
 
 
 class TGRUBlock(_ComplexBlock):
-    """GRU along time over the interleaved (channel, re/im) features of every (batch, frequency) row (torch's
-    device GRU), then complex 1x1 conv + complex BatchNorm + ReLU as one launch (UDSS.py:39-70)."""
+    """GRU along time over the interleaved (channel, re/im) features of every (batch, frequency) row (one persistent
+    recurrence launch, unet_amd.gru), then complex 1x1 conv + complex BatchNorm + ReLU as one launch (UDSS.py:39-70)."""
 
     def __init__(self, in_channels, hidden_size, out_channels, skipGRU=False, **kwargs):
         super().__init__()
@@ -311,7 +312,7 @@ class TGRUBlock(_ComplexBlock):
         B, C2, F, T = x.shape
         C = C2 // 2
         seq = x.reshape(B, 2, C, F, T).permute(0, 3, 4, 2, 1).reshape(B * F, T, C2)      # feature index c*2 + re/im
-        y, _ = self.GRU(seq.float(), rnn_state)
+        y, _ = _gru.run(self.GRU, seq.float(), rnn_state)
         H = self.hidden_size
         y = y.reshape(B, F, T, H, 2).permute(0, 4, 3, 1, 2).reshape(B, 2 * H, F, T).contiguous().to(x.dtype)
         return self._stacked(self.conv, y)
@@ -365,8 +366,8 @@ class FTGRUBlock(nn.Module):
 
 
 class cRNN(nn.Module):
-    """Four real GRUs combined as a complex recurrence, BatchNorm1d and PReLU per part (UDSS.py:190-239); torch's
-    device RNN and elementwise ops on the stacked tensor."""
+    """Four real GRUs combined as a complex recurrence, BatchNorm1d and PReLU per part (UDSS.py:190-239); the GRUs
+    through unet_amd.gru, elementwise ops on the stacked tensor."""
 
     def __init__(self, dim, style="GRU"):
         super().__init__()
@@ -384,8 +385,9 @@ class cRNN(nn.Module):
         B, C2, F, T = x.shape
         C = C2 // 2
         parts = x.float().reshape(B, 2, C * F, T).permute(1, 0, 3, 2)                      # [2, B, T, C*F]
-        rr, ri = self.rr(parts[0])[0], self.ri(parts[0])[0]
-        ir, ii = self.ir(parts[1])[0], self.ii(parts[1])[0]
+        cell = _gru.run if isinstance(self.rr, nn.GRU) else (lambda rnn, seq: rnn(seq))
+        rr, ri = cell(self.rr, parts[0])[0], cell(self.ri, parts[0])[0]
+        ir, ii = cell(self.ir, parts[1])[0], cell(self.ii, parts[1])[0]
         re = self.re_activation(self.re_norm(torch.permute(rr - ii, (0, 2, 1))))           # [B, C*F, T]
         im = self.im_activation(self.im_norm(torch.permute(ri + ir, (0, 2, 1))))
         # the reference permutes the 4-D [B, C*F, T, 2] tensor with (1, 3, 2, 0) -- giving [C*F, 2, T, B] -- and then

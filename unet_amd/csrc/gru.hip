@@ -1,0 +1,190 @@
+// Recurrent part of the GRU bottlenecks (DSUNet.py:281-312 TGRUBlock: nn.GRU(128, 128); UDSS.py TGRUBlock /
+// cRNN: nn.GRU(256, 512), nn.GRU(256, 256)) as ONE persistent kernel per layer instead of several launches per
+// time step, in the mould of the projected-LSTM kernel (lstm.hip):
+//
+//     r = sigmoid(gx_r + W_hr h + b_hr)     z = sigmoid(gx_z + W_hz h + b_hz)
+//     n = tanh(gx_n + r * (W_hn h + b_hn))  h' = (1 - z) * n + z * h
+//
+// gx = W_ih x + b_ih for all steps is one large product outside this kernel.  Workgroup j owns hidden units
+// 4j..4j+3: its 12 rows of W_hh (3 gates x 4 units, padded to the 16 rows of v_mfma_f32_16x16x4_f32) stay in LDS
+// in operand order for all T steps; per step each of its 4 waves multiplies a quarter of the K range (B operand
+// = h_{t-1}, read from L2 with device-coherent loads), the partial sums meet in LDS, 4 x batch threads apply the
+// gates and write the new state rows, and the H/4 workgroups meet at a device-wide barrier of per-workgroup flag
+// words.  The barrier spin is bounded: after the limit the workgroup raises an abort flag that releases all
+// others, every state row from the aborted step on is NaN and the flag stays raised in sync[nwg] for the caller.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <string>
+
+#include "../../include/unetmi.h"
+
+namespace unetmi {
+
+int api_fail(int code, const std::string& msg);
+
+typedef float gru_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned kGruSpinLimit = 1u << 21;
+
+struct GruArgs {
+    const float* whh;      // [3H][H], gate order r, z, n (torch's weight_hh_l0)
+    const float* bhh;      // [3H]
+    const float* gx;       // [T][3H][BP] input contribution incl. b_ih
+    float* hfull;          // [T+1][H][BP]; slot 0 = initial state, step t reads slot t and writes slot t+1
+    unsigned* sync;        // [nwg] step each workgroup has finished, then [1] abort flag
+    int T, BP, nwg;
+};
+
+__device__ __forceinline__ float gru_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// device-wide barrier over co-resident workgroups: own flag word per workgroup, wave 0 polls them all
+__device__ __forceinline__ bool gru_grid_barrier(unsigned* flags, int nwg, unsigned step, int* s_flag) {
+    // the state-row stores must have been acknowledged before the flag is raised
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        if (tid == 0) __hip_atomic_store(&flags[blockIdx.x], step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        for (;;) {
+            bool here = true;
+            for (int i = tid; i < nwg; i += 64)
+                here = here && __hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= step;
+            if (__all(here)) break;
+            const unsigned stop = __hip_atomic_load(&flags[nwg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stop != 0u || ++spins > kGruSpinLimit) {
+                if (tid == 0) __hip_atomic_store(&flags[nwg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        if (tid == 0) *s_flag = ok;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+template <int NCT, int H>      // 16-column batch tiles: BP = 16 * NCT; hidden size (a multiple of 16)
+__global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(const GruArgs a) {
+    constexpr int BP = 16 * NCT;
+    constexpr int KS = H / 16;                        // 16x16x4 k-steps per wave (K split over 4 waves)
+    __shared__ float s_a[H / 4 * 64];                 // [k-step][lane] A operands: 16 rows (12 used) x H
+    __shared__ float s_p[4][16][BP + 1];              // per-wave partial sums of W_hh h
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u0 = blockIdx.x * 4;
+
+    // A operand of k-step ks, lane l: W_hh[row(l&15)][4*ks + (l>>4)], row r = gate (r>>2) of unit u0 + (r&3); rows 12..15 zero
+    for (int i = tid; i < H / 4 * 64; i += 256) {
+        const int l = i & 63, ks = i >> 6, r = l & 15;
+        s_a[i] = r < 12 ? a.whh[(size_t)((r >> 2) * H + u0 + (r & 3)) * H + 4 * ks + (l >> 4)] : 0.f;
+    }
+    // gate thread: unit u0 + cu, batch column cb; it carries that element of the state in a register
+    const int cu = tid / BP, cb = tid - cu * BP;
+    const bool gate_thread = tid < 4 * BP;
+    float bh[3] = {0.f, 0.f, 0.f};
+    float h = 0.f;
+    if (gate_thread) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bh[g] = a.bhh[g * H + u0 + cu];
+        h = a.hfull[(size_t)(u0 + cu) * BP + cb];
+    }
+    __syncthreads();
+
+    int t = 0;
+    for (; t < a.T; ++t) {
+        const float* hprev = a.hfull + (size_t)t * H * BP;
+        gru_f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = gru_f32x4{0.f, 0.f, 0.f, 0.f};
+        float bv[KS][NCT];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                bv[ks][ct] = __hip_atomic_load(&hprev[(size_t)(4 * (wave * KS + ks) + (lane >> 4)) * BP + ct * 16 + (lane & 15)],
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float gxv[3] = {0.f, 0.f, 0.f};               // this step's input contribution, fetched while the MFMAs run
+        if (gate_thread) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gxv[g] = a.gx[((size_t)t * 3 * H + g * H + u0 + cu) * BP + cb];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float av = s_a[(wave * KS + ks) * 64 + lane];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[ks][ct], acc[ct], 0, 0, 0);
+        }
+        // D: col = lane&15, row = 4*(lane>>4) + i
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_p[wave][4 * (lane >> 4) + i][ct * 16 + (lane & 15)] = acc[ct][i];
+        __syncthreads();
+        if (gate_thread) {
+            float gh[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                gh[g] = bh[g] + ((s_p[0][g * 4 + cu][cb] + s_p[1][g * 4 + cu][cb]) + (s_p[2][g * 4 + cu][cb] + s_p[3][g * 4 + cu][cb]));
+            const float r = gru_sigmoid(gxv[0] + gh[0]), z = gru_sigmoid(gxv[1] + gh[1]);
+            const float n = tanhf(gxv[2] + r * gh[2]);
+            h = (1.f - z) * n + z * h;
+            __hip_atomic_store(&a.hfull[((size_t)(t + 1) * H + u0 + cu) * BP + cb], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!gru_grid_barrier(a.sync, a.nwg, (unsigned)(t + 1), &s_flag)) break;
+    }
+    if (t < a.T && gate_thread)
+        for (int tt = t + 1; tt <= a.T; ++tt) a.hfull[((size_t)tt * H + u0 + cu) * BP + cb] = __builtin_nanf("");
+}
+
+template <int H>
+static int launch_gru(const GruArgs& a, int cus, hipStream_t s) {
+    int per_cu = 0;
+    hipError_t oe;
+    switch (a.BP / 16) {
+        case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_recurrence_kernel<1, H>, 256, 0); break;
+        case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_recurrence_kernel<2, H>, 256, 0); break;
+        case 3: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_recurrence_kernel<3, H>, 256, 0); break;
+        default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_recurrence_kernel<4, H>, 256, 0); break;
+    }
+    if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("gru_recurrence occupancy query: ") + hipGetErrorString(oe));
+    if ((long long)per_cu * cus < a.nwg)
+        return api_fail(UNETMI_E_UNSUPPORTED, "gru_recurrence: the device cannot hold all workgroups at once");
+    hipError_t e = hipMemsetAsync(a.sync, 0, (size_t)(a.nwg + 1) * sizeof(unsigned), s);
+    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("gru_recurrence memset: ") + hipGetErrorString(e));
+    switch (a.BP / 16) {
+        case 1: hipLaunchKernelGGL((gru_recurrence_kernel<1, H>), dim3(a.nwg), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((gru_recurrence_kernel<2, H>), dim3(a.nwg), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((gru_recurrence_kernel<3, H>), dim3(a.nwg), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((gru_recurrence_kernel<4, H>), dim3(a.nwg), dim3(256), 0, s, a); break;
+    }
+    e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("gru_recurrence launch: ") + hipGetErrorString(e));
+}
+
+}  // namespace unetmi
+
+using namespace unetmi;
+
+extern "C" int unetmi_gru_recurrence(int T, int BP, int H, const float* whh, const float* bhh, const float* gx,
+                                     float* hfull, void* sync_ws, void* stream) {
+    if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "gru_recurrence: bad sizes");
+    if (H != 128 && H != 256 && H != 512) return api_fail(UNETMI_E_UNSUPPORTED, "gru_recurrence: built for hidden sizes 128, 256 and 512");
+    if (BP % 16 != 0 || BP > 64) return api_fail(UNETMI_E_UNSUPPORTED, "gru_recurrence: padded batch must be 16, 32, 48 or 64");
+    if (T == 0) return UNETMI_OK;
+    if (!whh || !bhh || !gx || !hfull || !sync_ws) return api_fail(UNETMI_E_BAD_ARG, "gru_recurrence: null pointer");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return api_fail(UNETMI_E_HIP, "gru_recurrence: cannot query the device");
+    GruArgs a{};
+    a.whh = whh; a.bhh = bhh; a.gx = gx; a.hfull = hfull; a.sync = static_cast<unsigned*>(sync_ws);
+    a.T = T; a.BP = BP; a.nwg = H / 4;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (H == 128) return launch_gru<128>(a, cus, s);
+    if (H == 256) return launch_gru<256>(a, cus, s);
+    return launch_gru<512>(a, cus, s);
+}

@@ -393,6 +393,7 @@ _LIBRARY.define("adam_step(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Te
                 "float beta2, float eps, float weight_decay, float grad_scale, int step) -> ()")
 _LIBRARY.define("gather_f32(Tensor src, Tensor map) -> Tensor")
 _LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool xcd, bool channel_major) -> Tensor")
+_LIBRARY.define("gru_recurrence(Tensor whh, Tensor bhh, Tensor gx, Tensor(a!) hfull) -> Tensor")
 _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
 _LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
 _LIBRARY.define("conv2d_b16_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
@@ -581,6 +582,25 @@ def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major):
         return sync[-1].clone()
 
 
+def _gru_recurrence_cuda(whh, bhh, gx, hfull):
+    """One GRU layer's T dependent steps: gx [T, 3H, BP] (input contributions + b_ih), whh [3H, H], bhh [3H], hfull
+    [T+1, H, BP] with slot 0 = the initial state; fills hfull[1:].  Returns the status word as a device scalar."""
+    for t, name in ((whh, "whh"), (bhh, "bhh"), (gx, "gx"), (hfull, "hfull")):
+        _dev(t, name, "gru_recurrence")
+    T, G, BP = gx.shape
+    H = G // 3
+    if G != 3 * H or tuple(whh.shape) != (G, H) or bhh.numel() != G or tuple(hfull.shape) != (T + 1, H, BP):
+        raise ValueError("unetmi::gru_recurrence: whh [3H,H], bhh [3H], gx [T,3H,BP], hfull [T+1,H,BP] expected")
+    key = (gx.device, "gru", H)
+    sync = _lstm_scratch.get(key)
+    if sync is None:
+        sync = _lstm_scratch[key] = torch.empty(H // 4 + 1, dtype=torch.int32, device=gx.device)
+    with torch.cuda.device(gx.device):
+        check(_lib.lib.unetmi_gru_recurrence(T, BP, H, _ptr(whh), _ptr(bhh), _ptr(gx), _ptr(hfull), _ptr(sync), _stream(gx)),
+              "unetmi_gru_recurrence")
+    return sync[-1].clone()
+
+
 def blocks_for(C):
     return 2 * ((C + 15) // 16)
 
@@ -669,7 +689,7 @@ def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param
 for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_batch_stats", _bn_batch_stats_cuda),
                    ("bn_running_update", _bn_running_update_cuda), ("bn_act_fwd", _bn_act_fwd_cuda),
                    ("bn_act_bwd", _bn_act_bwd_cuda), ("conv2d_wgrad", _conv2d_wgrad_cuda),
-                   ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda),
+                   ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda), ("gru_recurrence", _gru_recurrence_cuda),
                    ("blocked_from_nchw", _blocked_from_nchw_cuda), ("nchw_from_blocked", _nchw_from_blocked_cuda),
                    ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda)):
     _LIBRARY.impl(_name, _fn, "CUDA")
@@ -722,6 +742,11 @@ def _(wrec, gx, hfull, xcd, channel_major):
     return gx.new_empty((), dtype=torch.int32)
 
 
+@torch.library.register_fake("unetmi::gru_recurrence")
+def _(whh, bhh, gx, hfull):
+    return gx.new_empty((), dtype=torch.int32)
+
+
 @torch.library.register_fake("unetmi::blocked_from_nchw")
 def _(x):
     N, C, H, W = x.shape
@@ -753,6 +778,7 @@ conv2d_wgrad = torch.ops.unetmi.conv2d_wgrad
 adam_step = torch.ops.unetmi.adam_step
 gather_f32 = torch.ops.unetmi.gather_f32
 lstm_recurrence = torch.ops.unetmi.lstm_recurrence
+gru_recurrence = torch.ops.unetmi.gru_recurrence
 blocked_from_nchw = torch.ops.unetmi.blocked_from_nchw
 nchw_from_blocked = torch.ops.unetmi.nchw_from_blocked
 conv2d_b16_fwd = torch.ops.unetmi.conv2d_b16_fwd
