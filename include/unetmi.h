@@ -150,6 +150,16 @@ int unetmi_dwconv2d_fwd(int N, int C, int H, int W, int kh, int kw, int ph, int 
                         const void* in, const void* in2, const float* weight, const float* bias, void* out,
                         int dtype, void* stream);
 
+/* Weight and bias gradient of that depthwise convolution for train mode (autograd through UNet_m.py:546-548):
+ *   dweight[c][0][r][s] = sum_{n,y,x} dout[n,c,y,x] * (in [+ in2])[n,c, y-ph+r*dh, x-pw+s*dw],  dbias[c] = sum dout
+ * in/in2/dout: device fp32 [N,C,H,W]; dweight [C,1,kh,kw]; dbias [C] or null; ws: device scratch of
+ * unetmi_dwconv2d_wgrad_workspace_bytes(C, kh, kw) bytes.  Sums are formed in a fixed order.  The input gradient
+ * is unetmi_dwconv2d_fwd applied to dout with the taps of each channel reversed. */
+size_t unetmi_dwconv2d_wgrad_workspace_bytes(int C, int kh, int kw);
+int unetmi_dwconv2d_wgrad(int N, int C, int H, int W, int kh, int kw, int ph, int pw, int dh, int dw, const float* in,
+                          const float* in2, const float* dout, float* dweight, float* dbias, void* ws, size_t ws_bytes,
+                          void* stream);
+
 /* One layer of UNet_m.ResBlock, fused (C = 64):
  *   out = [x (+ x2) +] BN(PReLU(Conv2d(C,C,1)(Conv2d(C,C,(3,3),pad (1,d),dil (1,d),groups=C)(x (+ x2)))))
  * replacing, per layer, the depthwise conv, the pointwise conv, the shared PReLU, the BatchNorm2d

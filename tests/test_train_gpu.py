@@ -2,6 +2,7 @@
 against the golden training step recorded from the reference."""
 
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -404,3 +405,165 @@ def test_dsunet_train_step_matches_oracle(device):
             assert_close(v.detach().cpu(), after_ref[k], tol=1e-5, what="running statistic " + k)
     print("DSUNet train step: loss {:.6f}; {} of {} pre-activations on the other side of zero; worst gradient error "
           "{:.2e} of its tensor's scale".format(loss.item(), flips[0], flips[1], worst))
+
+
+def _gradients_against_float64(dev_net, ref, run, what, floor=1e-2):
+    """Train-mode loss, gradients and BatchNorm running statistics of ``dev_net`` (on the device) against the oracle
+    ``ref``.  ``run(net, cast)`` returns the scalar loss of a network on inputs converted by ``cast``.
+
+    PReLU's and LeakyReLU's derivatives jump at zero, and the device's pre-activations differ from the CPU's in the
+    last bits, so a handful among millions land on the other side of zero; each moves the gradient sums it feeds by
+    up to 1e-2 of their value (the CPU's own fp32 autograd is that far from float64 autograd on these networks).
+    The gradients are therefore compared with float64 autograd of the oracle run WITH THE DEVICE'S ACTIVATION
+    PATTERN -- the sign of every pre-activation, captured call by call from the device forward -- to 1e-4 of each
+    tensor's largest entry; the number of pre-activations whose sign differs from the oracle's own is reported and
+    bounded."""
+    import unet_amd
+    ref64 = copy.deepcopy(ref).double().train()
+    ref.train()
+    loss_ref = run(ref, lambda t: t)
+
+    dev_net.train()
+    patterns = {}
+
+    def capture_input(name):
+        return lambda mod, inp, out: patterns.setdefault(name, []).append((inp[0].detach() >= 0).cpu())
+
+    def capture_output(name):
+        return lambda mod, inp, out: patterns.setdefault(name, []).append((out.detach() >= 0).cpu())
+    handles = []
+    for name, m in dev_net.named_modules():
+        if isinstance(m, nn.PReLU):                              # runs as a torch module in train mode
+            handles.append(m.register_forward_hook(capture_input(name)))
+        elif isinstance(m, (unet_amd.Encoder, unet_amd.Decoder)) and isinstance(m.acti, nn.LeakyReLU):
+            handles.append(m.register_forward_hook(capture_output(name + ".acti")))   # inside the fused node: sign of the output
+    loss = run(dev_net, lambda t: t.to(next(dev_net.parameters()).device))
+    loss.backward()
+    for h in handles:
+        h.remove()
+    assert abs(loss.item() - loss_ref.item()) <= 2e-5 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+
+    flips, calls = [0, 0], {}
+
+    def device_pattern(name):
+        def hook(mod, inp, out):
+            k = calls.get(name, 0)
+            calls[name] = k + 1
+            pre, mask = inp[0], patterns[name][k]
+            flips[0] += int(((pre >= 0) != mask).sum())
+            flips[1] += pre.numel()
+            slope = mod.weight if isinstance(mod, nn.PReLU) else torch.tensor(mod.negative_slope, dtype=pre.dtype)
+            return pre * torch.where(mask, torch.ones((), dtype=pre.dtype), slope)
+        return hook
+    for name, m in ref64.named_modules():
+        if isinstance(m, (nn.PReLU, nn.LeakyReLU)):
+            if isinstance(m, nn.LeakyReLU):
+                m.inplace = False              # the hook needs the pre-activation as it was
+            assert name in patterns, "no device pattern for " + name
+            m.register_forward_hook(device_pattern(name))
+    run(ref64, lambda t: t.double()).backward()
+    assert {k: len(v) for k, v in patterns.items()} == calls
+    assert flips[0] <= max(2, 2e-5 * flips[1]), flips
+    exact = {k: p.grad for k, p in ref64.named_parameters()}
+    gmax = max(g.abs().max().item() for g in exact.values() if g is not None)
+    worst = 0.0
+    report, failures = [], []
+    for k, p in dev_net.named_parameters():
+        if exact[k] is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
+            continue
+        assert p.grad is not None, "no gradient for " + k
+        g = p.grad.detach().cpu().double()
+        scale = max(exact[k].abs().max().item(), floor * gmax)
+        err = (g - exact[k]).abs().max().item()
+        worst = max(worst, err / scale)
+        report.append((err / scale, k))
+        if err > 1e-4 * scale:
+            failures.append("grad {}: err {:.3e}, scale {:.3e}".format(k, err, scale))
+    if os.environ.get("UNETMI_TEST_VERBOSE") == "1":
+        for e, k in sorted(report, reverse=True)[:25]:
+            print("  {:50s} {:.2e}".format(k, e))
+    assert not failures, failures[:5]
+    after_ref = ref.state_dict()
+    for k, v in dev_net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert_close(v.detach().cpu(), after_ref[k], tol=1e-5, what="running statistic " + k)
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(after_ref[k]), k
+    print("{}: loss {:.6f}; {} of {} pre-activations on the other side of zero than the oracle's; worst gradient "
+          "error {:.2e} of its tensor's scale".format(what, loss.item(), flips[0], flips[1], worst))
+
+
+@pytest.mark.parametrize("kernel,dilation", [((3, 3), (1, 1)), ((3, 3), (1, 4)), ((1, 3), (1, 2)), ((3, 1), (2, 1))])
+def test_depthwise_conv_gradients(device, kernel, dilation):
+    """Autograd of unetmi::dwconv2d_fwd (the depthwise convolution of a ResBlock layer, UNet_m.py:546-548): input,
+    addend, weight and bias gradients against float64 autograd of torch's grouped convolution."""
+    import torch.nn.functional as F
+    from unet_amd.ops import dwconv2d_fwd
+    C = 12
+    pad = [dilation[0] * (kernel[0] - 1) // 2, dilation[1] * (kernel[1] - 1) // 2]
+    x, x2 = _rand((3, C, 9, 37), 5), _rand((3, C, 9, 37), 6)
+    w, b, g = _rand((C, 1) + kernel, 7, 0.5), _rand((C,), 8), _rand((3, C, 9, 37), 9)
+    leaves64 = [t.double().requires_grad_() for t in (x, x2, w, b)]
+    F.conv2d(leaves64[0] + leaves64[1], leaves64[2], leaves64[3], 1, pad, dilation, C).backward(g.double())
+    leaves = [t.to(device).requires_grad_() for t in (x, x2, w, b)]
+    out = dwconv2d_fwd(leaves[0], leaves[1], leaves[2], leaves[3], pad, list(dilation))
+    out.backward(g.to(device))
+    for name, a, e in zip(("x", "x2", "weight", "bias"), leaves, leaves64):
+        assert_close(a.grad.cpu(), e.grad.float(), tol=2e-5, what="depthwise conv gradient of " + name)
+
+
+@pytest.mark.parametrize("channels", [64, 30])
+def test_resblock_train_step_matches_oracle(device, channels):
+    """ResBlock in train() mode (UNet_m.py:518-563 under autograd): five layers of depthwise conv, pointwise conv,
+    the shared PReLU and BatchNorm with batch statistics, at the width of ResUNet (64) and of ResUNetOnFreq (30)."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    ref = oracle.ResBlock(channels)
+    unet_amd.seeded_fill_(ref, seed=61)
+    dev_net = unet_amd.ResBlock(channels)
+    dev_net.load_state_dict(ref.state_dict(), strict=True)
+    dev_net.to(device)
+    x = normal("resblock_train/x", (2, channels, 17, 40), seed=62)
+    target = normal("resblock_train/target", (2, channels, 17, 40), seed=63)
+    _gradients_against_float64(dev_net, ref, lambda net, cast: torch.mean((net(cast(x)) - cast(target)) ** 2),
+                               "ResBlock({}) train step".format(channels))
+
+
+def test_resunet_train_step_matches_oracle(device):
+    """ResUNet in train() mode (ResUNet.py:161-220 under autograd) at B=2, T=16: input layers, ResBlocks, PReLU
+    encoders / decoders, 1x1 res paths, the projected LSTM (torch's device LSTM under autograd), additive skips, head
+    and mask.  Loss, every gradient and the running statistics against the oracle."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    ref = oracle.ResUNet(c_in=4, c_out=1)
+    unet_amd.seeded_fill_(ref, seed=71)
+    dev_net = unet_amd.ResUNet(c_in=4, c_out=1)
+    dev_net.load_state_dict(ref.state_dict(), strict=True)
+    dev_net.to(device)
+    x = normal("resunet_train/x", (2, 4, 257, 16), seed=72)
+    target = normal("resunet_train/target", (2, 2, 257, 16), seed=73)
+    _gradients_against_float64(dev_net, ref, lambda net, cast: torch.mean((net(cast(x)) - cast(target)) ** 2),
+                               "ResUNet train step")
+
+
+@pytest.mark.parametrize("variant", ["ResUNetOnFreq", "ResUNetOnFreq2"])
+def test_resunet_on_freq_train_step_matches_oracle(device, variant):
+    """The 30-channel variants in train() mode (ResUNet.py:227-389, :394-591 under autograd), Softplus mask;
+    ResUNetOnFreq2 includes the reference's ``self.bottleneck(x)[0]`` (sample 0's bottleneck output for the whole
+    batch), whose gradient autograd sums back onto sample 0."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    c_in = 4 if variant == "ResUNetOnFreq" else 1
+    ref = getattr(oracle, variant)(c_in=c_in, c_out=1)
+    unet_amd.seeded_fill_(ref, seed=81)
+    dev_net = getattr(unet_amd, variant)(c_in=c_in, c_out=1)
+    dev_net.load_state_dict(ref.state_dict(), strict=True)
+    dev_net.to(device)
+    x = normal("onfreq_train/x", (2, c_in, 257, 12), seed=82)
+    target = normal("onfreq_train/target", (2, 1, 257, 12), seed=83)
+    _gradients_against_float64(dev_net, ref, lambda net, cast: torch.mean((net(cast(x)) - cast(target)) ** 2),
+                               variant + " train step")

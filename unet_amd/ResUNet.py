@@ -25,6 +25,8 @@ from .ops import layernorm_f, tanh_mask_mul
 def _trunk(net, x, bottleneck=None):
     """Encoders, projected-LSTM bottleneck, 1x1 res-paths and the additive-skip decoders shared by
     ResUNet, ResUNetOnFreq and ResUNetOnFreq2 (ResUNet.py:176-215 == :344-381 == :543-580)."""
+    if net.training:
+        return _trunk_train(net, x, bottleneck)
     res = []
     for i, enc in enumerate(net.encoders):
         x = enc(x)
@@ -69,6 +71,35 @@ def _trunk(net, x, bottleneck=None):
         if net.print_shape:
             print("y_{} : {}".format(i, y.shape))
     return y
+
+
+def _trunk_train(net, x, bottleneck=None):
+    """The same trunk in train() mode, as the reference writes it (ResUNet.py:176-210): every block records autograd
+    history (convolutions and BatchNorm on the library's kernels, see UNet_m._FusedBlock._run_differentiable and
+    ResBlock._forward_train), the skip adds are torch additions, and the LSTM is torch's device LSTM, whose backward
+    autograd provides (the persistent recurrence kernel is inference only)."""
+    res = []
+    for enc in net.encoders:
+        x = enc(x)
+        res.append(x)
+    if bottleneck is not None:
+        y = bottleneck(x)
+    else:
+        seq = x.reshape(x.shape[0], x.shape[1], x.shape[3]).permute(0, 2, 1)
+        seq = net.bottleneck(seq.contiguous())[0]
+        y = seq.permute(0, 2, 1).reshape(x.shape[0], x.shape[1], 1, x.shape[3])
+    for i, rp in enumerate(net.res_paths):
+        res[i] = rp(res[i])
+    for i, dec in enumerate(net.decoders):
+        y = dec(y + res[-1 - i])
+    return y
+
+
+def _head_train(net, y):
+    """The output layer (a bare transposed convolution) under autograd: forward and both gradients on the library's kernels."""
+    from . import _lib
+    from .train import conv_norm_act
+    return conv_norm_act(net.out_layer, None, _lib.ACT_NONE, None, y.contiguous())
 
 
 class ResUNet(nn.Module):
@@ -131,7 +162,7 @@ class ResUNet(nn.Module):
     def forward(self, input):
         require_device_tensor(input, "ResUNet")
         if self.training:
-            raise NotImplementedError("ResUNet: train-mode forward is not available in this build; call .eval()")
+            return self._forward_train(input)
         if input.dtype == torch.bfloat16 and not self.bf16_storage:
             return self.forward(input.float()).to(torch.bfloat16)
         B, _, F, T = input.shape
@@ -148,6 +179,18 @@ class ResUNet(nn.Module):
             # on widened tensors and only the final product is rounded
             return tanh_mask_mul(self._out(y.float()), input.float().contiguous(), 1e-13).to(y.dtype)
         return tanh_mask_mul(self._out(y), input.contiguous(), 1e-13)
+
+
+    def _forward_train(self, input):
+        """ResUNet.py:161-220 under autograd: the input layers see the [B,C,T,F] view as in the reference (conv +
+        BatchNorm + LeakyReLU as one node, LayerNorm(257) as torch's), then the trunk, head and mask."""
+        if input.dtype != torch.float32:
+            raise NotImplementedError("ResUNet: train mode is fp32 only")
+        feature = self.layer_data(input[:, :-2].permute(0, 1, 3, 2).contiguous()).permute(0, 1, 3, 2)
+        af = self.layer_AF(input[:, -2:].permute(0, 1, 3, 2).contiguous()).permute(0, 1, 3, 2)
+        y = _trunk_train(self, torch.cat((feature, af), dim=1))
+        mask = self.last_activation(_head_train(self, y)) + 1e-13
+        return mask * input[:, :2]
 
 
 class ResUNetOnFreq(nn.Module):
@@ -209,8 +252,11 @@ class ResUNetOnFreq(nn.Module):
 
     def forward(self, input):
         require_device_tensor(input, "ResUNetOnFreq")
-        if self.training:
-            raise NotImplementedError("ResUNetOnFreq: train-mode forward is not available in this build; call .eval()")
+        if self.training:                      # ResUNet.py:336-386 under autograd
+            if input.dtype != torch.float32:
+                raise NotImplementedError("ResUNetOnFreq: train mode is fp32 only")
+            x = self.layer_input(input.permute(0, 1, 3, 2).contiguous()).permute(0, 1, 3, 2)
+            return self.activation_mask(_head_train(self, _trunk_train(self, x)))
         B, _, F, T = input.shape
         x = torch.empty((B, 30, F, T), dtype=input.dtype, device=input.device)
         ResUNet._input_branch(self, self.layer_input, "_in", input.contiguous(), x, 0)
@@ -246,7 +292,7 @@ class LSTMBlock(nn.Module):
         require_device_tensor(x, "LSTMBlock")
         B, C, F, T = x.shape
         seq = x.reshape(B, C * F, T).permute(0, 2, 1)
-        if lstm_supported(self.rnn):             # hidden size 300 / 640: one persistent recurrence launch per layer
+        if lstm_supported(self.rnn) and not self.training:   # hidden size 300 / 640: one persistent recurrence launch per layer
             y = lstm_forward(self.rnn, seq.float().contiguous(), self._lstm_cache).to(x.dtype)
         else:
             y = self.rnn(seq.float())[0].to(x.dtype)
@@ -334,8 +380,13 @@ class ResUNetOnFreq2(nn.Module):
 
     def forward(self, input):
         require_device_tensor(input, "ResUNetOnFreq2")
-        if self.training:
-            raise NotImplementedError("ResUNetOnFreq2: train-mode forward is not available in this build; call .eval()")
+        if self.training:                      # ResUNet.py:530-586 under autograd
+            if self.activation == "MEA" or input.dtype != torch.float32:
+                raise NotImplementedError("ResUNetOnFreq2: train mode is built for fp32 inputs and the single-mask activations")
+            x = self.layer_input(input.permute(0, 1, 3, 2).contiguous()).permute(0, 1, 3, 2)
+            # ``self.bottleneck(x)[0]`` on a tensor: sample 0's output, which the skip add then broadcasts over the batch
+            y = _trunk_train(self, x, lambda t: self.bottleneck(t)[0])
+            return self.activation_mask(_head_train(self, y))
         B, _, F, T = input.shape
         x = torch.empty((B, 30, F, T), dtype=input.dtype, device=input.device)
         ResUNet._input_branch(self, self.layer_input, "_in", input.contiguous(), x, 0)

@@ -62,10 +62,7 @@ class _FusedBlock(nn.Module):
     def _run(self, x, skip=None, in_mode=None, gate=None, residual=None):
         require_device_tensor(x, type(self).__name__)
         if self.training:
-            if residual is not None:
-                raise NotImplementedError("{}: differentiable forward with an added tensor is not built".format(
-                    type(self).__name__))
-            return self._run_differentiable(x, skip, in_mode, gate)
+            return self._run_differentiable(x, skip, in_mode, gate, residual)
         layer = self._layer()
         if layer.fusable():
             return layer(x, skip, in_mode=in_mode, gate=gate, residual=residual)
@@ -80,25 +77,43 @@ class _FusedBlock(nn.Module):
             y = y + residual
         return y
 
-    def _run_differentiable(self, x, skip, in_mode, gate):
-        """train() mode: batch statistics, and forward and backward are HIP launches recorded as
-        one autograd node (unet_amd/train.py).  eval() mode is inference only: its output carries
-        no autograd history."""
+    def _run_differentiable(self, x, skip, in_mode, gate, residual):
+        """train() mode: the convolution, the BatchNorm (batch statistics) and an activation the epilogue knows by
+        code are HIP launches recorded as one autograd node (unet_amd/train.py: forward, input gradient and weight
+        gradient on the library's kernels).  What that node does not cover stays a torch operation on the device, so
+        that autograd differentiates it: an activation with a learnable parameter (PReLU), another norm
+        (InstanceNorm2d / LayerNorm), dropout between convolution and norm, a summed skip, a gate, an added tensor.
+        eval() mode is inference only: its output carries no autograd history."""
         from .fused import activation_code
-        from .train import conv_norm_act
-        who = type(self).__name__
+        from .train import batch_norm_act, conv_norm_act
+        conv = getattr(self, self._conv_attr)
         found = activation_code(self.acti)
-        if found is None or isinstance(found[1], torch.Tensor):
-            raise NotImplementedError("{}: differentiable forward is not built for {}".format(
-                who, type(self.acti).__name__))
-        if gate is not None or (in_mode is not None and in_mode != _lib.IN_CONCAT):
-            raise NotImplementedError("{}: differentiable forward with a gate or a summed skip is not built".format(who))
-        drop = getattr(self, "dropout", None)
-        if drop is not None and drop.p != 0.0 and self.training:
-            raise NotImplementedError("{}: dropout with p > 0 is not built".format(who))
-        code, par = found
+        by_code = found is not None and not isinstance(found[1], torch.Tensor)
+        code, par = found if by_code else (_lib.ACT_NONE, None)
         act_param = None if par is None else torch.full((1,), par, dtype=torch.float32, device=x.device)
-        return conv_norm_act(getattr(self, self._conv_attr), self.bn, code, act_param, x, skip)
+        if skip is not None and in_mode == _lib.IN_ADD:
+            x, skip = x + skip, None
+        drop = getattr(self, "dropout", None)
+        dropping = drop is not None and drop.p != 0.0
+        plain_norm = isinstance(self.bn, (nn.BatchNorm2d, nn.Identity))
+        if plain_norm and not dropping:
+            y = conv_norm_act(conv, self.bn, code, act_param, x.contiguous(), skip)
+        else:
+            z = conv_norm_act(conv, None, _lib.ACT_NONE, None, x.contiguous(), skip)
+            if dropping:
+                z = drop(z)
+            if isinstance(self.bn, nn.BatchNorm2d):
+                y = batch_norm_act(self.bn, z, code, act_param)
+            else:
+                y = self.bn(z)
+                by_code = False                         # the activation follows as a torch operation
+        if not by_code:
+            y = self.acti(y)
+        if gate is not None:
+            y = y * gate[:, :, None, None]
+        if residual is not None:
+            y = y + residual
+        return y
 
 
 class Encoder(_FusedBlock):
@@ -183,7 +198,7 @@ class ResBlock(nn.Module):
     def forward(self, x, add=None):
         require_device_tensor(x, "ResBlock")
         if self.training:
-            raise NotImplementedError("ResBlock: train-mode forward is not available in this build; call .eval()")
+            return self._forward_train(x, add)
         if self._fused is None:
             object.__setattr__(self, "_fused", [FusedConv(l[1], l[3], l[2], act_first=True) for l in self.layers])
         if x.shape[1] == 64 and self.layers[0][2].weight.numel() == 1:
@@ -195,6 +210,22 @@ class ResBlock(nn.Module):
             t = dwconv2d_fwd(src, add if i == 0 else None, dw.weight.float(), None if dw.bias is None else dw.bias.float(),
                              list(_pair(dw.padding)), list(_pair(dw.dilation)))
             r = self._fused[i](t, residual=r)        # layer 0 has no running value to add
+        return r
+
+    def _forward_train(self, x, add):
+        """train() mode under autograd: per layer the depthwise convolution (unetmi::dwconv2d_fwd; its input gradient
+        is the same kernel with reversed taps, its weight gradient unetmi_dwconv2d_wgrad), the pointwise convolution
+        (unetmi::conv_norm_act without norm: forward, input and weight gradient on the MFMA kernels), the shared PReLU
+        (a torch operation, so its slope gets a gradient) and BatchNorm with batch statistics (unetmi::bn_act)."""
+        from .train import batch_norm_act, conv_norm_act
+        r = None
+        for i, layer in enumerate(self.layers):
+            dw, pw, act, bn = layer[0], layer[1], layer[2], layer[3]
+            src = (x if i == 0 else r).contiguous()
+            t = dwconv2d_fwd(src, add.contiguous() if (i == 0 and add is not None) else None, dw.weight, dw.bias,
+                             list(_pair(dw.padding)), list(_pair(dw.dilation)))
+            y = batch_norm_act(bn, act(conv_norm_act(pw, None, _lib.ACT_NONE, None, t)))
+            r = y if i == 0 else r + y
         return r
 
     def _forward_one_launch_per_layer(self, x, add):

@@ -23,6 +23,8 @@ EXPORTED_SYMBOLS = (
     "unetmi_conv2d_pack_weights",
     "unetmi_conv2d_fwd",
     "unetmi_dwconv2d_fwd",
+    "unetmi_dwconv2d_wgrad_workspace_bytes",
+    "unetmi_dwconv2d_wgrad",
     "unetmi_layernorm_f_fwd",
     "unetmi_tanh_mask_mul",
     "unetmi_crf_apply",
@@ -95,6 +97,10 @@ def _load():
     lib.unetmi_conv2d_fwd.restype = ctypes.c_int
     ci, cf = ctypes.c_int, ctypes.c_float
     lib.unetmi_dwconv2d_fwd.argtypes = [ci] * 10 + [fp] * 5 + [ci, vp]
+    lib.unetmi_dwconv2d_wgrad_workspace_bytes.argtypes = [ci] * 3
+    lib.unetmi_dwconv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.unetmi_dwconv2d_wgrad.argtypes = [ci] * 10 + [fp] * 5 + [vp, ctypes.c_size_t, vp]
+    lib.unetmi_dwconv2d_wgrad.restype = ctypes.c_int
     lib.unetmi_layernorm_f_fwd.argtypes = [ci] * 6 + [cf] + [fp] * 4 + [ci, vp]
     lib.unetmi_tanh_mask_mul.argtypes = [ci] * 5 + [cf] + [fp] * 3 + [ci, vp]
     lib.unetmi_crf_apply.argtypes = [ci] * 7 + [fp] * 3 + [vp]

@@ -48,7 +48,8 @@ struct WgradArgs {
     int R;           // rows of the ring
     int win;         // rows a step reads: (kh-1)*dh + 1
     int nqc;         // column strips per sample
-    int strips, spw; // N*nqc, strips per workgroup
+    int nrs, rps;    // row segments per column strip, P rows per segment
+    int strips, spw; // N*nqc*nrs, strips per workgroup
     int ntaps, npairs;
     int nq_items;    // sh*BT*qcols elements staged per step
     int ring_bias;   // multiple of R added before the modulo so negative rows map consistently
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
     int buf = 0;
     const int st_lo = blockIdx.x * g.spw, st_hi = min(st_lo + g.spw, g.strips);
     for (int st = st_lo; st < st_hi; ++st) {
-        const int n = st / g.nqc, q0 = (st - n * g.nqc) * kTQ;
+        const int cs = st / g.nrs, seg = st - cs * g.nrs;          // column strip, row segment within it
+        const int n = cs / g.nqc, q0 = (cs - n * g.nqc) * kTQ;
+        const int p_lo = seg * g.rps, p_hi = min(p_lo + g.rps, g.PH);
         const auto rs_p = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(psrc + (size_t)n * a_cnt * g.PH * g.PW), 0, a_cnt * g.PH * g.PW * 4, 0x00020000);
         const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(
@@ -161,13 +164,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
             }
         };
 
-        // prologue: the window of step 0 and its P tile
-        const int base0 = -g.ph;
+        // prologue: the window of the segment's first step and its P tile
+        const int base0 = p_lo * g.sh - g.ph;
         for (int y = base0; y < base0 + g.win; y += g.sh) {
             load_q(y);
             store_q(y);
         }
-        load_p(0);
+        load_p(p_lo);
         store_p(buf);
         __syncthreads();
 
@@ -175,9 +178,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) rowoff[j] = ((base0 + pair_row[j] + g.ring_bias) % g.R) * rowstride + pair_off[j] + lb;
 
-        for (int p = 0; p < g.PH; ++p) {
-            const int ynew = base0 + p * g.sh + g.win;       // first row step p+1 needs beyond this window
-            const bool more = p + 1 < g.PH;
+        for (int p = p_lo; p < p_hi; ++p) {
+            const int ynew = p * g.sh - g.ph + g.win;        // first row step p+1 needs beyond this window
+            const bool more = p + 1 < p_hi;
             if (more) {
                 load_p(p + 1);
                 load_q(ynew);
@@ -279,8 +282,14 @@ static int plan_wgrad(int N, int A0, int A1, int B, int PH, int PW, int QH, int 
     pl->bgroups = (B + a.BT - 1) / a.BT;
     pl->ablocks = (A0 + 63) / 64 + (A1 + 63) / 64;
     a.nqc = (PW + kTQ - 1) / kTQ;
-    a.strips = N * a.nqc;
     const int G = pl->bgroups * pl->ablocks;
+    // a small batch of wide layers has few column strips: cut each into row segments (>= 16 rows, each pays one
+    // window of prologue rows) until the grid holds two workgroups per CU
+    a.nrs = 1;
+    while (N * a.nqc * a.nrs * G < 512 && PH / (a.nrs + 1) >= 16) ++a.nrs;
+    a.rps = (PH + a.nrs - 1) / a.nrs;
+    a.nrs = (PH + a.rps - 1) / a.rps;
+    a.strips = N * a.nqc * a.nrs;
     int splits = std::min(a.strips, std::max(1, (768 + G - 1) / G));
     a.spw = (a.strips + splits - 1) / splits;
     pl->splits = (a.strips + a.spw - 1) / a.spw;

@@ -392,6 +392,7 @@ _LIBRARY.define("conv2d_wgrad(Tensor in0, Tensor? in1, Tensor dout, int[] geom, 
 _LIBRARY.define("adam_step(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, "
                 "float beta2, float eps, float weight_decay, float grad_scale, int step) -> ()")
 _LIBRARY.define("gather_f32(Tensor src, Tensor map) -> Tensor")
+_LIBRARY.define("dwconv2d_wgrad(Tensor x, Tensor? x2, Tensor dout, int[] kernel, int[] padding, int[] dilation) -> (Tensor, Tensor)")
 _LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool xcd, bool channel_major) -> Tensor")
 _LIBRARY.define("gru_recurrence(Tensor whh, Tensor bhh, Tensor gx, Tensor(a!) hfull) -> Tensor")
 _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
@@ -582,6 +583,26 @@ def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major):
         return sync[-1].clone()
 
 
+def _dwconv2d_wgrad_cuda(x, x2, dout, kernel, padding, dilation):
+    """(dweight [C,1,kh,kw], dbias [C]) of the depthwise 'same' convolution that dwconv2d_fwd computes."""
+    _dev(x, "x", "dwconv2d_wgrad"), _dev(dout, "dout", "dwconv2d_wgrad")
+    if x2 is not None:
+        _dev(x2, "x2", "dwconv2d_wgrad")
+    if dout.shape != x.shape or (x2 is not None and x2.shape != x.shape):
+        raise ValueError("unetmi::dwconv2d_wgrad: x, x2 and dout must have one shape")
+    N, C, H, W = x.shape
+    kh, kw = kernel
+    dweight = torch.empty((C, 1, kh, kw), dtype=torch.float32, device=x.device)
+    dbias = torch.empty((C,), dtype=torch.float32, device=x.device)
+    need = _lib.lib.unetmi_dwconv2d_wgrad_workspace_bytes(C, kh, kw)
+    ws = workspace(x.device, need)
+    with torch.cuda.device(x.device):
+        check(_lib.lib.unetmi_dwconv2d_wgrad(N, C, H, W, kh, kw, padding[0], padding[1], dilation[0], dilation[1], _ptr(x),
+                                             _ptr(x2), _ptr(dout), _ptr(dweight), _ptr(dbias), _ptr(ws), need, _stream(x)),
+              "unetmi_dwconv2d_wgrad")
+    return dweight, dbias
+
+
 def _gru_recurrence_cuda(whh, bhh, gx, hfull):
     """One GRU layer's T dependent steps: gx [T, 3H, BP] (input contributions + b_ih), whh [3H, H], bhh [3H], hfull
     [T+1, H, BP] with slot 0 = the initial state; fills hfull[1:].  Returns the status word as a device scalar."""
@@ -689,7 +710,7 @@ def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param
 for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_batch_stats", _bn_batch_stats_cuda),
                    ("bn_running_update", _bn_running_update_cuda), ("bn_act_fwd", _bn_act_fwd_cuda),
                    ("bn_act_bwd", _bn_act_bwd_cuda), ("conv2d_wgrad", _conv2d_wgrad_cuda),
-                   ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda), ("gru_recurrence", _gru_recurrence_cuda),
+                   ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda), ("gru_recurrence", _gru_recurrence_cuda), ("dwconv2d_wgrad", _dwconv2d_wgrad_cuda),
                    ("blocked_from_nchw", _blocked_from_nchw_cuda), ("nchw_from_blocked", _nchw_from_blocked_cuda),
                    ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda)):
     _LIBRARY.impl(_name, _fn, "CUDA")
@@ -742,6 +763,11 @@ def _(wrec, gx, hfull, xcd, channel_major):
     return gx.new_empty((), dtype=torch.int32)
 
 
+@torch.library.register_fake("unetmi::dwconv2d_wgrad")
+def _(x, x2, dout, kernel, padding, dilation):
+    return x.new_empty((x.shape[1], 1, kernel[0], kernel[1])), x.new_empty((x.shape[1],))
+
+
 @torch.library.register_fake("unetmi::gru_recurrence")
 def _(whh, bhh, gx, hfull):
     return gx.new_empty((), dtype=torch.int32)
@@ -779,6 +805,7 @@ adam_step = torch.ops.unetmi.adam_step
 gather_f32 = torch.ops.unetmi.gather_f32
 lstm_recurrence = torch.ops.unetmi.lstm_recurrence
 gru_recurrence = torch.ops.unetmi.gru_recurrence
+dwconv2d_wgrad = torch.ops.unetmi.dwconv2d_wgrad
 blocked_from_nchw = torch.ops.unetmi.blocked_from_nchw
 nchw_from_blocked = torch.ops.unetmi.nchw_from_blocked
 conv2d_b16_fwd = torch.ops.unetmi.conv2d_b16_fwd

@@ -257,15 +257,118 @@ def conv_norm_act(conv, norm, act_code, act_param, x, skip=None):
         bn.running_mean if mode == 2 else None, bn.running_var if mode == 2 else None, list(geom), bool(transposed),
         mode, bn.eps if bn is not None else 0.0, act_code, act_param)
     if mode == 1:
-        with torch.no_grad():
-            count = z.numel() // z.shape[1]
-            _ops.bn_running_update(bn.running_mean, bn.running_var, mean, invstd, count, bn.eps, bn.momentum)
-            # written through raw pointers: tell torch they changed
-            torch.autograd.graph.increment_version(bn.running_mean)
-            torch.autograd.graph.increment_version(bn.running_var)
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+        _bn_bookkeeping(bn, z, mean, invstd)
     return y
+
+
+# ---------------------------------------------------------------------------------------
+# unetmi::bn_act -- BatchNorm2d + activation of a tensor that is already there (the residual block normalises AFTER
+# its PReLU, UNet_m.py:545-551; a block with dropout normalises the dropped-out convolution): the norm half of
+# conv_norm_act as a functional op of its own, same kernels, same modes.
+# ---------------------------------------------------------------------------------------
+_ops._LIBRARY.define(
+    "bn_act(Tensor z, Tensor? gamma, Tensor? beta, Tensor? running_mean, Tensor? running_var, int norm_mode, float eps, "
+    "int act, Tensor? act_param) -> (Tensor, Tensor, Tensor)")
+
+
+def _bn_act_cuda(z, gamma, beta, running_mean, running_var, norm_mode, eps, act, act_param):
+    z = z.contiguous()
+    K, dev = z.shape[1], z.device
+    if norm_mode == 1:
+        mean, invstd = _ops.bn_batch_stats(z, eps)
+    else:
+        mean = running_mean.detach().clone()
+        invstd = torch.rsqrt(running_var.detach() + eps)
+    g = gamma.detach() if gamma is not None else _constant(1.0, K, dev)
+    b = beta.detach() if beta is not None else _constant(0.0, K, dev)
+    return _ops.bn_act_fwd(z, mean, invstd, g, b, act, act_param), mean, invstd
+
+
+_ops._LIBRARY.impl("bn_act", _bn_act_cuda, "CUDA")
+
+
+@torch.library.register_fake("unetmi::bn_act")
+def _(z, gamma, beta, running_mean, running_var, norm_mode, eps, act, act_param):
+    return torch.empty_like(z), z.new_empty((z.shape[1],)), z.new_empty((z.shape[1],))
+
+
+def _bn_act_setup(ctx, inputs, output):
+    z, gamma, beta, _, _, norm_mode, _, act, act_param = inputs
+    _, mean, invstd = output
+    ctx.norm_mode, ctx.act = norm_mode, act
+    ctx.has = (gamma is not None, beta is not None)
+    ctx.set_materialize_grads(False)
+    ctx.save_for_backward(z, mean, invstd, gamma, beta, act_param)
+
+
+def _bn_act_backward(ctx, dy, dmean_unused, dinvstd_unused):
+    z, mean, invstd, gamma, beta, act_param = ctx.saved_tensors
+    if dy is None:
+        return (None,) * 9
+    z = z.contiguous()
+    K, dev = z.shape[1], z.device
+    g = gamma.detach() if gamma is not None else _constant(1.0, K, dev)
+    b = beta.detach() if beta is not None else _constant(0.0, K, dev)
+    dz, dgamma, dbeta, _ = bn_act_bwd(dy.contiguous(), z, mean, invstd, g, b, ctx.act, act_param, ctx.norm_mode == 1)
+    need = ctx.needs_input_grad
+    return (dz if need[0] else None, dgamma if (ctx.has[0] and need[1]) else None,
+            dbeta if (ctx.has[1] and need[2]) else None) + (None,) * 6
+
+
+torch.library.register_autograd("unetmi::bn_act", _bn_act_backward, setup_context=_bn_act_setup)
+
+
+def _bn_bookkeeping(bn, z, mean, invstd):
+    """What a train-mode BatchNorm2d forward does beside normalising: running statistics and the batch counter."""
+    with torch.no_grad():
+        count = z.numel() // z.shape[1]
+        _ops.bn_running_update(bn.running_mean, bn.running_var, mean, invstd, count, bn.eps, bn.momentum)
+        torch.autograd.graph.increment_version(bn.running_mean)      # written through raw pointers
+        torch.autograd.graph.increment_version(bn.running_var)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+
+
+def batch_norm_act(bn, z, act_code=_lib.ACT_NONE, act_param=None):
+    """Differentiable nn.BatchNorm2d ``bn`` (+ an activation by its epilogue code) of ``z`` on the library's kernels:
+    batch statistics and bookkeeping in train mode, the running statistics in eval mode."""
+    batch_stats = bn.training or bn.running_mean is None
+    if batch_stats and (bn.momentum is None or not bn.track_running_stats):
+        raise NotImplementedError("train-mode BatchNorm2d needs a numeric momentum and tracked running statistics")
+    mode = 1 if batch_stats else 2
+    y, mean, invstd = torch.ops.unetmi.bn_act(z, bn.weight, bn.bias, bn.running_mean if mode == 2 else None,
+                                              bn.running_var if mode == 2 else None, mode, bn.eps, act_code, act_param)
+    if mode == 1:
+        _bn_bookkeeping(bn, z, mean, invstd)
+    return y
+
+
+# ---------------------------------------------------------------------------------------
+# autograd of unetmi::dwconv2d_fwd (the depthwise 'same' convolution of a residual-block layer): the input gradient
+# is the same kernel on the output gradient with each channel's taps reversed, the weight / bias gradient is
+# unetmi_dwconv2d_wgrad.
+# ---------------------------------------------------------------------------------------
+def _dwconv_setup(ctx, inputs, output):
+    x, x2, weight, bias, padding, dilation = inputs
+    ctx.padding, ctx.dilation = list(padding), list(dilation)
+    ctx.has = (x2 is not None, bias is not None)
+    ctx.save_for_backward(x, x2, weight)
+
+
+def _dwconv_backward(ctx, dy):
+    x, x2, weight = ctx.saved_tensors
+    need = ctx.needs_input_grad
+    dy = dy.contiguous()
+    dx = dweight = dbias = None
+    if need[0] or (ctx.has[0] and need[1]):
+        dx = _ops.dwconv2d_fwd(dy, None, weight.detach().flip(2, 3).contiguous(), None, ctx.padding, ctx.dilation)
+    if need[2] or (ctx.has[1] and need[3]):
+        dweight, dbias = _ops.dwconv2d_wgrad(x, x2, dy, [weight.shape[2], weight.shape[3]], ctx.padding, ctx.dilation)
+    return (dx if need[0] else None, dx if (ctx.has[0] and need[1]) else None, dweight if need[2] else None,
+            dbias if (ctx.has[1] and need[3]) else None, None, None)
+
+
+torch.library.register_autograd("unetmi::dwconv2d_fwd", _dwconv_backward, setup_context=_dwconv_setup)
 
 
 # ---------------------------------------------------------------------------------------
