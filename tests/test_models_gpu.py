@@ -224,8 +224,6 @@ def test_dau_matches_golden_and_oracle(device, label, kw):
     assert_close(got, want, what="DAU {} HIP vs oracle".format(label))
     assert_close(torch.view_as_real(got.cpu()), torch.from_numpy(load_golden("dau_eval")[label]),
                  what="DAU {} HIP vs golden".format(label))
-    with pytest.raises(NotImplementedError):
-        dev.train()(sf.to(device), SV.to(device), theta.to(device))
     for bad, exc in ((dict(bottleneck="TGRU"), Exception), (dict(activation="PReLU"), TypeError)):
         with pytest.raises(exc):
             unet_amd.DAU(**bad)

@@ -51,21 +51,29 @@ class _Block(nn.Module):
 
     def _run_differentiable(self, conv, x, skip, gate):
         """train() mode (the reference's blocks are trained under stock autograd, DSUNet.py:62-93, :174-200):
-        convolution, BatchNorm with batch statistics and activation are one autograd node whose forward and
-        backward are HIP launches (unet_amd/train.py); the gate product stays a torch operation, so its gradient
-        reaches the attractor's Linears."""
-        from .train import conv_norm_act
-        who = type(self).__name__
+        convolution, BatchNorm with batch statistics and an activation known by code are one autograd node whose
+        forward and backward are HIP launches (unet_amd/train.py); the gate product stays a torch operation, so its
+        gradient reaches the attractor's Linears.  PReLU (a learnable slope), InstanceNorm2d and dropout between
+        convolution and norm are torch operations around the convolution node."""
+        from .train import batch_norm_act, conv_norm_act
         found = activation_code(self.relu)
-        if not isinstance(self.bn, nn.BatchNorm2d) or found is None or isinstance(found[1], torch.Tensor):
-            raise NotImplementedError("{}: train-mode forward is built for BatchNorm2d with LeakyReLU / SiLU / Softplus "
-                                      "(got {} / {})".format(who, type(self.bn).__name__, type(self.relu).__name__))
-        drop = getattr(self, "dr", None)
-        if drop is not None and drop.p != 0.0:
-            raise NotImplementedError("{}: dropout with p > 0 is not built".format(who))
-        code, par = found
+        by_code = found is not None and not isinstance(found[1], torch.Tensor)
+        code, par = found if by_code else (_lib.ACT_NONE, None)
         act_param = None if par is None else torch.full((1,), par, dtype=torch.float32, device=x.device)
-        y = conv_norm_act(conv, self.bn, code, act_param, x, skip)
+        drop = getattr(self, "dr", None)
+        dropping = drop is not None and drop.p != 0.0
+        if isinstance(self.bn, nn.BatchNorm2d) and not dropping:
+            y = conv_norm_act(conv, self.bn, code, act_param, x.contiguous(), skip)
+        else:
+            z = conv_norm_act(conv, None, _lib.ACT_NONE, None, x.contiguous(), skip)
+            if dropping:
+                z = drop(z)
+            if isinstance(self.bn, nn.BatchNorm2d):
+                y = batch_norm_act(self.bn, z, code, act_param)
+            else:
+                y, by_code = self.bn(z), False
+        if not by_code:
+            y = self.relu(y)
         return y if gate is None else y * gate[:, :, None, None]
 
 
@@ -144,12 +152,11 @@ class _Gated(nn.Module):
 
     def _gated(self, x, skip, norm, act, gate):
         require_device_tensor(x, type(self).__name__)
-        if self.training:
-            raise NotImplementedError("{}: train-mode forward is not available in this build; call .eval()"
-                                      .format(type(self).__name__))
         c, m = self.c, self.m[0]
         if c.groups != 1:
             raise NotImplementedError("grouped gated convolutions are not built")
+        if self.training:
+            return self._gated_train(c, m, x, skip, norm, act, gate)
         z = self._stacked(c, m)(x, skip)
         scale = shift = None
         post_norm = None
@@ -172,6 +179,31 @@ class _Gated(nn.Module):
         elif par is not None:
             par = torch.full((1,), par, dtype=torch.float32, device=x.device)
         return glu(z, scale, shift, code, par, gate)
+
+
+    def _gated_train(self, c, m, x, skip, norm, act, gate):
+        """train() mode: the two convolutions are ONE differentiable node on the stacked weight (assembled from the
+        parameters by torch.cat, so its gradient splits back onto them); the sigmoid gate product, a norm other
+        than BatchNorm2d and the activation are torch operations; BatchNorm2d runs the library's kernels with batch
+        statistics."""
+        from .train import batch_norm_act
+        transposed = isinstance(c, nn.ConvTranspose2d)
+        K = c.out_channels
+        W = torch.cat([c.weight, m.weight], dim=1 if transposed else 0).contiguous()
+        zero = torch.zeros(K, device=W.device)
+        bias = torch.cat([c.bias if c.bias is not None else zero, m.bias if m.bias is not None else zero])
+        geom, _ = FusedConv(c).geometry()
+        geom = [2 * K] + list(geom[1:])
+        z = torch.ops.unetmi.conv_norm_act(x.contiguous(), None if skip is None else skip.contiguous(), W, bias, None,
+                                           None, None, None, geom, transposed, 0, 0.0, _lib.ACT_NONE, None)[0]
+        y = z[:, :K] * torch.sigmoid(z[:, K:])
+        if isinstance(norm, nn.BatchNorm2d):
+            y = batch_norm_act(norm, y.contiguous())
+        elif norm is not None:
+            y = norm(y)
+        if act is not None:
+            y = act(y)
+        return y if gate is None else y * gate[:, :, None, None]
 
 
 class GConv(_Gated):
@@ -233,10 +265,13 @@ class TGRUBlock(nn.Module):
         x_ = x.permute(0, 2, 3, 1).reshape(B * F, T, C)
         y_, rnn_state = _gru.run(self.GRU, x_.float(), rnn_state)
         y2 = y_.reshape(B, F, T, self.hidden_size).permute(0, 3, 1, 2).contiguous().to(x.dtype)
+        if self.training:                    # the GRU above ran torch's device GRU (autograd); conv + BN + ReLU: one node
+            from .train import conv_norm_act
+            return conv_norm_act(self.conv, self.bn, _lib.ACT_RELU, None, y2)
         if self._fused is None:
             object.__setattr__(self, "_fused", FusedConv(self.conv, self.bn, self.relu))
-        if self.training or not self._fused.fusable():
-            raise NotImplementedError("TGRUBlock: eval-mode BatchNorm only")
+        if not self._fused.fusable():
+            raise NotImplementedError("TGRUBlock: BatchNorm2d only")
         return self._fused(y2)
 
 

@@ -67,9 +67,7 @@ class DAU(nn.Module):
 
     def forward(self, sf, SV, theta):
         require_device_tensor(sf, "DAU")
-        if self.training:
-            raise NotImplementedError("DAU: train-mode forward is not available in this build; call .eval()")
-        return self._core(sf, SV, theta)
+        return self._core(sf, SV, theta)          # train() mode: UDSS._forward_train, every block under autograd
 
 
 class DAU_helper(UDSS_helper):

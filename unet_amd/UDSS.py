@@ -221,6 +221,81 @@ class _ComplexLayer:
         return self._twin(C0, C1)(x, skip, gate=gate)
 
 
+def _complex_train(cconv, cbn, act, x, skip=None, gate=None, dropout=None):
+    """A complex block on stacked tensors in train() mode, under autograd: the block weight
+    [[W_re, -W_im], [W_im, W_re]] and the bias pair are assembled from the parameters by torch operations (so the
+    gradient of the stacked weight flows back to the two real convolutions' parameters), and the convolution, the
+    two BatchNorm2d (batch statistics; stacked they are one BatchNorm over 2K channels) and an activation known by
+    code are one ``unetmi::conv_norm_act`` node -- forward, input gradient and weight gradient on the HIP kernels.
+    A learnable activation (PReLU), dropout between convolution and norm, and the gate are torch operations."""
+    from . import _lib
+    from . import ops as _ops
+    from .fused import activation_code
+    from .train import _bn_bookkeeping  # noqa: F401  (same bookkeeping, applied per part below)
+    re, im = cconv.parts()
+    transposed = isinstance(re, nn.ConvTranspose2d)
+    if re.groups != 1:
+        raise NotImplementedError("grouped complex convolutions are not built")
+    if cbn is not None and not isinstance(cbn, ComplexBatchNorm2d):
+        raise NotImplementedError("complex block: train mode is built for ComplexBatchNorm2d")
+    ia, oa = (0, 1) if transposed else (1, 0)
+    C0 = x.shape[1] // 2
+    C1 = 0 if skip is None else skip.shape[1] // 2
+    Wr, Wi = re.weight, im.weight
+    if Wr.shape[ia] != C0 + C1:
+        raise ValueError("complex layer built for {} input channels, got {} + {}".format(Wr.shape[ia], C0, C1))
+    Wr0, Wr1 = Wr.narrow(ia, 0, C0), Wr.narrow(ia, C0, C1)
+    Wi0, Wi1 = Wi.narrow(ia, 0, C0), Wi.narrow(ia, C0, C1)
+    W = torch.cat([torch.cat([Wr0, -Wi0, Wr1, -Wi1], dim=ia), torch.cat([Wi0, Wr0, Wi1, Wr1], dim=ia)], dim=oa).contiguous()
+    K = Wr.shape[oa]
+    zero = torch.zeros(K, device=W.device)
+    br = re.bias if re.bias is not None else zero
+    bi = im.bias if im.bias is not None else zero
+    bias = torch.cat([br - bi, br + bi])
+    geom, _ = FusedConv(re).geometry()
+    geom = [2 * K] + list(geom[1:])
+    found = activation_code(act)
+    by_code = found is not None and not isinstance(found[1], torch.Tensor)
+    code, par = found if by_code else (_lib.ACT_NONE, None)
+    act_param = None if par is None else torch.full((1,), par, dtype=torch.float32, device=x.device)
+    dropping = dropout is not None and dropout.p != 0.0
+    parts = () if cbn is None else (cbn.bn_re, cbn.bn_im)
+    for bn in parts:
+        if not bn.track_running_stats or bn.momentum is None or not bn.affine:
+            raise NotImplementedError("complex block: train mode needs affine BatchNorm2d with tracked statistics")
+    gamma = torch.cat([bn.weight for bn in parts]) if parts else None
+    beta = torch.cat([bn.bias for bn in parts]) if parts else None
+    eps = parts[0].eps if parts else 0.0
+    x = x.contiguous()
+    skip = None if skip is None else skip.contiguous()
+    if parts and not dropping:
+        y, z, mean, invstd = torch.ops.unetmi.conv_norm_act(x, skip, W, bias, gamma, beta, None, None, geom, transposed,
+                                                            1, eps, code, act_param)
+    else:
+        z = torch.ops.unetmi.conv_norm_act(x, skip, W, bias, None, None, None, None, geom, transposed, 0, 0.0,
+                                           code if not parts else _lib.ACT_NONE, act_param if not parts else None)[0]
+        y = z
+        if dropping:
+            z = dropout(z)
+        if parts:
+            y, mean, invstd = torch.ops.unetmi.bn_act(z, gamma, beta, None, None, 1, eps, code, act_param)
+    if parts:
+        with torch.no_grad():
+            count = z.numel() // z.shape[1]
+            for h, bn in enumerate(parts):
+                _ops.bn_running_update(bn.running_mean, bn.running_var, mean[h * K:(h + 1) * K].contiguous(),
+                                       invstd[h * K:(h + 1) * K].contiguous(), count, bn.eps, bn.momentum)
+                torch.autograd.graph.increment_version(bn.running_mean)
+                torch.autograd.graph.increment_version(bn.running_var)
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+    if not by_code:
+        y = act(y)
+    if gate is not None:
+        y = y * torch.cat([gate, gate], dim=1)[:, :, None, None]
+    return y
+
+
 def _norm_cls(type_norm):
     # UDSS.py:358-361: any other name leaves the class unbound in the reference (UnboundLocalError)
     if type_norm == "BatchNorm2d":
@@ -237,8 +312,7 @@ def _activation(name):
 class _ComplexBlock(nn.Module):
     def _stacked(self, cconv, x, skip=None, gate=None):
         if self.training:
-            raise NotImplementedError("{}: train-mode forward is not available in this build; call .eval()"
-                                      .format(type(self).__name__))
+            return _complex_train(cconv, self.bn, self.relu, x, skip, gate, getattr(self, "dr", None))
         if not isinstance(self.bn, ComplexBatchNorm2d):
             raise NotImplementedError("{}: only ComplexBatchNorm2d (eval) is fused".format(type(self).__name__))
         if self._layer is None:
@@ -451,6 +525,11 @@ class CMEA(nn.Module):
         if self._fused is None:
             object.__setattr__(self, "_fused", tuple(FusedConv(m) for m in (self.mag_mask, self.real_mask, self.imag_mask)))
         mag = torch.sqrt(re ** 2 + im ** 2).contiguous()
+        if self.training:                  # the three thin convolutions as differentiable nodes
+            from . import _lib
+            from .train import conv_norm_act
+            return tuple(conv_norm_act(m, None, _lib.ACT_NONE, None, t.contiguous()).squeeze(1)
+                         for m, t in zip((self.mag_mask, self.real_mask, self.imag_mask), (mag, re, im)))
         return tuple(f(t.contiguous()).squeeze(1) for f, t in zip(self._fused, (mag, re, im)))
 
     def forward(self, x):
@@ -560,10 +639,10 @@ class UDSS(nn.Module):
 
     def forward(self, sf, SV, theta):
         require_device_tensor(sf, "UDSS")
-        if self.training:
-            raise NotImplementedError("UDSS: train-mode forward is not available in this build; call .eval()")
         if sf.dim() != 5 or sf.shape[-1] != 2:
             raise ValueError("UDSS: sf must be [B, C, F, T, 2]")
+        if self.training:
+            return self._forward_train(sf, SV, theta)
         attract = self.Attractor(SV.float(), theta.float())
         L = self.model_length
         if sf.dtype == torch.bfloat16:
@@ -584,6 +663,26 @@ class UDSS(nn.Module):
             act = nn.Tanh() if isinstance(self.mask, CRM) else None
             object.__setattr__(self, "_head", _ComplexLayer(self.linear, None, act))
         m = self._head(p).float()                                       # [B, 2, F, T]: re, im (squashed for CRM)
+        if isinstance(self.mask, CMEA):
+            return self.mask.from_parts(m[:, 0:1], m[:, 1:2])
+        return torch.complex(m[:, 0, ...], m[:, 1, ...])
+
+    def _forward_train(self, sf, SV, theta):
+        """UDSS.py:561-580 under autograd: every complex block is one differentiable node on the HIP kernels
+        (_complex_train); the attractor, its gates, the recurrent bottlenecks and the mask are torch operations."""
+        if sf.dtype != torch.float32:
+            raise NotImplementedError("UDSS: train mode is fp32 only")
+        attract = self.Attractor(SV.float(), theta.float())
+        L = self.model_length
+        x = stack_complex(sf)
+        skips = []
+        for i, enc in enumerate(self.encoders):
+            skips.append(x)
+            x = enc.forward_stacked(x, self.attractEncoders[i](attract).float())
+        p = x if isinstance(self.BTN, nn.Identity) else self.BTN.forward_stacked(x)
+        for i, dec in enumerate(self.decoders):
+            p = dec.forward_stacked(p, None if i == 0 else skips[L - i])
+        m = _complex_train(self.linear, None, nn.Tanh() if isinstance(self.mask, CRM) else None, p)
         if isinstance(self.mask, CMEA):
             return self.mask.from_parts(m[:, 0:1], m[:, 1:2])
         return torch.complex(m[:, 0, ...], m[:, 1, ...])
