@@ -203,14 +203,16 @@ int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float*
 
 /* The recurrence of a single-layer, unidirectional nn.GRU (DSUNet.py:281-312 TGRUBlock: GRU(128,128); UDSS.py's
  * TGRUBlock GRU(256,512) and cRNN GRU(256,256)) as one persistent launch.  The caller supplies
- *   gx[t][g*H+u][b] = (W_ih x_t + b_ih)[g*H+u] for all t   (gate order r, z, n: torch's weight_ih_l0 / bias_ih_l0)
+ *   gx[t][g*H+u][b] = (W_ih x_t + b_ih)[g*H+u] for all t   (gate order r, z, n: torch's weight_ih_l0 / bias_ih_l0),
+ *   laid out [T][3H][BP], or with gx_channel_major != 0 as [3H][T][BP] (what a 1x1 convolution over a
+ *   [channels, T, BP] image writes)
  *   whh[3H][H] = weight_hh_l0, bhh[3H] = bias_hh_l0
  * and hfull [T+1][H][BP] with slot 0 = the initial state; the kernel fills slots 1..T with h_1..h_T (the GRU's
  * outputs).  BP = batch padded to a multiple of 16 (<= 64); sync_ws: 4 * (H/4 + 1) bytes of device scratch
  * (cleared by the call), whose last word is non-zero after an aborted run (all state rows from the aborted step on
  * are then NaN).  H must be 128, 256 or 512; all H/4 workgroups have to be resident at once (checked). */
-int unetmi_gru_recurrence(int T, int BP, int H, const float* whh, const float* bhh, const float* gx, float* hfull,
-                          void* sync_ws, void* stream);
+int unetmi_gru_recurrence(int T, int BP, int H, const float* whh, const float* bhh, const float* gx,
+                          int gx_channel_major, float* hfull, void* sync_ws, void* stream);
 
 /* The same recurrence with the batch split over the chip's 8 XCDs (4 batch columns each, BP <= 32): every XCD runs
  * an independent recurrence for its columns, the state exchange stays inside that XCD's L2 and there is no

@@ -314,7 +314,7 @@ def test_every_entry_point_is_a_dispatcher_op_with_shape_inference():
         assert dwg.shape == (8, 1, 3, 3) and dbg.shape == (8,)
         yb, mb, ib = torch.ops.unetmi.bn_act(z, c, c, None, None, 1, 1e-5, 0, None)
         assert yb.shape == z.shape and mb.shape == ib.shape == (8,)
-        status = ops.gru_recurrence(torch.empty(384, 128), torch.empty(384), torch.empty(5, 384, 16), torch.empty(6, 128, 16))
+        status = ops.gru_recurrence(torch.empty(384, 128), torch.empty(384), torch.empty(5, 384, 16), torch.empty(6, 128, 16), False)
         assert status.shape == () and status.dtype == torch.int32
         b = ops.blocked_from_nchw(z)
         assert b.shape == (2, 2, 5, 7, 8) and b.dtype == torch.bfloat16

@@ -747,15 +747,18 @@ def test_projected_lstm_hidden_300(device, shape, B, T):
 
 
 @pytest.mark.parametrize("n_in,hidden", [(128, 128), (256, 512), (256, 256)])
-@pytest.mark.parametrize("B,T,with_state", [(4, 33, False), (32, 12, True), (130, 7, True)])
-def test_gru_recurrence(device, n_in, hidden, B, T, with_state):
+@pytest.mark.parametrize("B,T,with_state,gemm", [(4, 33, False, "conv"), (32, 12, True, "conv"), (130, 7, True, "conv"),
+                                                 (32, 12, True, "blas")])
+def test_gru_recurrence(device, n_in, hidden, B, T, with_state, gemm, monkeypatch):
     """The GRUs of the TGRU bottlenecks (DSUNet.py:290: GRU(128, 128); UDSS.py:48: GRU(256, 512)) and of cRNN
     (UDSS.py:197-200: GRU(256, 256)) on the persistent recurrence kernel against torch's CPU GRU, with and without a
     caller's initial state, at batches below, at and beyond one launch's 64 columns."""
     import copy
     import unet_amd
+    import unet_amd.gru
     from unet_amd.gru import gru_forward, supported
     from unet_amd.seeding import normal
+    monkeypatch.setattr(unet_amd.gru, "GEMM", gemm)     # the input product: the library's 1x1 convolution, or torch.matmul
     ref = torch.nn.GRU(n_in, hidden, batch_first=True).eval()
     holder = torch.nn.Module()
     holder.gru = ref

@@ -125,7 +125,7 @@ def _load():
     lib.unetmi_lstm_recurrence_xcd_workspace_bytes.restype = ctypes.c_size_t
     lib.unetmi_lstm_recurrence_xcd.argtypes = [ci] * 3 + [fp] * 3 + [ci, vp, ctypes.c_size_t, vp]
     lib.unetmi_lstm_recurrence_xcd.restype = ctypes.c_int
-    lib.unetmi_gru_recurrence.argtypes = [ci] * 3 + [fp] * 4 + [vp, vp]
+    lib.unetmi_gru_recurrence.argtypes = [ci] * 3 + [fp] * 3 + [ci, fp, vp, vp]
     lib.unetmi_gru_recurrence.restype = ctypes.c_int
     lib.unetmi_glu_fwd.argtypes = [ci] * 3 + [fp] * 3 + [ci] + [fp] * 3 + [ci, vp]
     lib.unetmi_glu_fwd.restype = ctypes.c_int

@@ -30,7 +30,8 @@ constexpr unsigned kGruSpinLimit = 1u << 21;
 struct GruArgs {
     const float* whh;      // [3H][H], gate order r, z, n (torch's weight_hh_l0)
     const float* bhh;      // [3H]
-    const float* gx;       // [T][3H][BP] input contribution incl. b_ih
+    const float* gx;       // input contribution incl. b_ih: element (t, row, b) at t*gx_step + row*gx_row + b
+    long long gx_step, gx_row;   // [T][3H][BP]: 3H*BP, BP;  channel-major [3H][T][BP]: BP, T*BP
     float* hfull;          // [T+1][H][BP]; slot 0 = initial state, step t reads slot t and writes slot t+1
     unsigned* sync;        // [nwg] step each workgroup has finished, then [1] abort flag
     int T, BP, nwg;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(const GruArgs a)
         float gxv[3] = {0.f, 0.f, 0.f};               // this step's input contribution, fetched while the MFMAs run
         if (gate_thread) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) gxv[g] = a.gx[((size_t)t * 3 * H + g * H + u0 + cu) * BP + cb];
+            for (int g = 0; g < 3; ++g) gxv[g] = a.gx[(size_t)t * a.gx_step + (size_t)(g * H + u0 + cu) * a.gx_row + cb];
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -171,7 +172,7 @@ static int launch_gru(const GruArgs& a, int cus, hipStream_t s) {
 using namespace unetmi;
 
 extern "C" int unetmi_gru_recurrence(int T, int BP, int H, const float* whh, const float* bhh, const float* gx,
-                                     float* hfull, void* sync_ws, void* stream) {
+                                     int gx_channel_major, float* hfull, void* sync_ws, void* stream) {
     if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "gru_recurrence: bad sizes");
     if (H != 128 && H != 256 && H != 512) return api_fail(UNETMI_E_UNSUPPORTED, "gru_recurrence: built for hidden sizes 128, 256 and 512");
     if (BP % 16 != 0 || BP > 64) return api_fail(UNETMI_E_UNSUPPORTED, "gru_recurrence: padded batch must be 16, 32, 48 or 64");
@@ -183,6 +184,8 @@ extern "C" int unetmi_gru_recurrence(int T, int BP, int H, const float* whh, con
     GruArgs a{};
     a.whh = whh; a.bhh = bhh; a.gx = gx; a.hfull = hfull; a.sync = static_cast<unsigned*>(sync_ws);
     a.T = T; a.BP = BP; a.nwg = H / 4;
+    a.gx_step = gx_channel_major ? BP : (long long)3 * H * BP;
+    a.gx_row = gx_channel_major ? (long long)T * BP : BP;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (H == 128) return launch_gru<128>(a, cus, s);
     if (H == 256) return launch_gru<256>(a, cus, s);

@@ -1,15 +1,22 @@
 """Single-layer unidirectional nn.GRU on the device (the TGRU bottlenecks, DSUNet.py:281-312 and UDSS.py:39-70, and
 the four GRUs of UDSS.py:190-239's cRNN).
 
-The input contribution of all time steps is one matrix product before the recurrence; the recurrence itself is one
+The input contribution of all time steps is one matrix product before the recurrence (a 1x1 convolution of the
+library's own kernel); the recurrence itself is one
 persistent HIP launch (unetmi_gru_recurrence) instead of several launches per time step.  Eval mode only (no
 autograd graph is recorded); a GRU in train mode stays on torch's device RNN.
 """
+
+import weakref
 
 import torch
 import torch.nn as nn
 
 from . import ops as _ops
+
+# The input product W_ih x of all steps: "conv" = a 1x1 convolution of the library's own kernel, "blas" = torch.matmul
+GEMM = "conv"
+_caches = weakref.WeakKeyDictionary()     # per GRU module: the packed input-weight image, rebuilt when a parameter changes
 
 MAX_BATCH_PER_LAUNCH = 64
 MAX_GROUPS = 8                    # beyond this many launches per call (batch > 512) the sequences are short and
@@ -43,15 +50,26 @@ def gru_forward(gru, x, h0=None):
     BP = (B + 15) // 16 * 16
     dev = x.device
     with torch.no_grad(), torch.cuda.device(dev):
-        seq = torch.zeros((T, x.shape[2], BP), dtype=torch.float32, device=dev)       # [T, in, BP]
-        seq[:, :, :B] = x.permute(1, 2, 0)
-        gx = torch.matmul(gru.weight_ih_l0.detach().float(), seq) + gru.bias_ih_l0.detach().float()[None, :, None]
         hfull = torch.empty((T + 1, H, BP), dtype=torch.float32, device=dev)
         hfull[0].zero_()
         if h0 is not None:
             hfull[0, :, :B] = h0[0].float().t()
-        aborted = _ops.gru_recurrence(gru.weight_hh_l0.detach().float().contiguous(),
-                                      gru.bias_hh_l0.detach().float().contiguous(), gx.contiguous(), hfull)
+        whh = gru.weight_hh_l0.detach().float().contiguous()
+        bhh = gru.bias_hh_l0.detach().float().contiguous()
+        if GEMM == "conv":
+            # the input product as a 1x1 convolution of the library's own kernel over a [channels, T, BP] image; the
+            # recurrence kernel reads its [3H, T, BP] result as it stands
+            from .lstm import _pointwise
+            seq = torch.zeros((1, x.shape[2], T, BP), dtype=torch.float32, device=dev)
+            seq[0, :, :, :B] = x.permute(2, 1, 0)
+            cache = _caches.setdefault(gru, {})
+            gx = _pointwise(gru.weight_ih_l0, gru.bias_ih_l0, cache, "ih")(seq)[0]
+            aborted = _ops.gru_recurrence(whh, bhh, gx, hfull, True)
+        else:
+            seq = torch.zeros((T, x.shape[2], BP), dtype=torch.float32, device=dev)       # [T, in, BP]
+            seq[:, :, :B] = x.permute(1, 2, 0)
+            gx = torch.matmul(gru.weight_ih_l0.detach().float(), seq) + gru.bias_ih_l0.detach().float()[None, :, None]
+            aborted = _ops.gru_recurrence(whh, bhh, gx.contiguous(), hfull, False)
         y = hfull[1:, :, :B].permute(2, 0, 1).contiguous()
         # a recurrence that gave up waiting must not pass for a result: NaN, without a host round trip
         y = torch.where(aborted != 0, torch.full_like(y, float("nan")), y)

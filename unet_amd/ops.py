@@ -394,7 +394,7 @@ _LIBRARY.define("adam_step(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Te
 _LIBRARY.define("gather_f32(Tensor src, Tensor map) -> Tensor")
 _LIBRARY.define("dwconv2d_wgrad(Tensor x, Tensor? x2, Tensor dout, int[] kernel, int[] padding, int[] dilation) -> (Tensor, Tensor)")
 _LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool xcd, bool channel_major) -> Tensor")
-_LIBRARY.define("gru_recurrence(Tensor whh, Tensor bhh, Tensor gx, Tensor(a!) hfull) -> Tensor")
+_LIBRARY.define("gru_recurrence(Tensor whh, Tensor bhh, Tensor gx, Tensor(a!) hfull, bool channel_major) -> Tensor")
 _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
 _LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
 _LIBRARY.define("conv2d_b16_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
@@ -603,22 +603,26 @@ def _dwconv2d_wgrad_cuda(x, x2, dout, kernel, padding, dilation):
     return dweight, dbias
 
 
-def _gru_recurrence_cuda(whh, bhh, gx, hfull):
-    """One GRU layer's T dependent steps: gx [T, 3H, BP] (input contributions + b_ih), whh [3H, H], bhh [3H], hfull
-    [T+1, H, BP] with slot 0 = the initial state; fills hfull[1:].  Returns the status word as a device scalar."""
+def _gru_recurrence_cuda(whh, bhh, gx, hfull, channel_major):
+    """One GRU layer's T dependent steps: gx [T, 3H, BP] (channel_major: [3H, T, BP]; input contributions + b_ih),
+    whh [3H, H], bhh [3H], hfull [T+1, H, BP] with slot 0 = the initial state; fills hfull[1:].  Returns the status
+    word as a device scalar."""
     for t, name in ((whh, "whh"), (bhh, "bhh"), (gx, "gx"), (hfull, "hfull")):
         _dev(t, name, "gru_recurrence")
-    T, G, BP = gx.shape
+    if channel_major:
+        G, T, BP = gx.shape
+    else:
+        T, G, BP = gx.shape
     H = G // 3
     if G != 3 * H or tuple(whh.shape) != (G, H) or bhh.numel() != G or tuple(hfull.shape) != (T + 1, H, BP):
-        raise ValueError("unetmi::gru_recurrence: whh [3H,H], bhh [3H], gx [T,3H,BP], hfull [T+1,H,BP] expected")
+        raise ValueError("unetmi::gru_recurrence: whh [3H,H], bhh [3H], gx [T,3H,BP] or [3H,T,BP], hfull [T+1,H,BP] expected")
     key = (gx.device, "gru", H)
     sync = _lstm_scratch.get(key)
     if sync is None:
         sync = _lstm_scratch[key] = torch.empty(H // 4 + 1, dtype=torch.int32, device=gx.device)
     with torch.cuda.device(gx.device):
-        check(_lib.lib.unetmi_gru_recurrence(T, BP, H, _ptr(whh), _ptr(bhh), _ptr(gx), _ptr(hfull), _ptr(sync), _stream(gx)),
-              "unetmi_gru_recurrence")
+        check(_lib.lib.unetmi_gru_recurrence(T, BP, H, _ptr(whh), _ptr(bhh), _ptr(gx), int(channel_major), _ptr(hfull),
+                                             _ptr(sync), _stream(gx)), "unetmi_gru_recurrence")
     return sync[-1].clone()
 
 
@@ -769,7 +773,7 @@ def _(x, x2, dout, kernel, padding, dilation):
 
 
 @torch.library.register_fake("unetmi::gru_recurrence")
-def _(whh, bhh, gx, hfull):
+def _(whh, bhh, gx, hfull, channel_major):
     return gx.new_empty((), dtype=torch.int32)
 
 
