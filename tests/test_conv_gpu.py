@@ -95,6 +95,53 @@ def test_conv_bn_act_matches_torch_cpu(device, geom):
     seq.cpu()
 
 
+# the MFMA rows of GEOMS with 33+ output channels (64-channel blocks), where both kernel families are built
+WIDE_GEOMS = [g for g in GEOMS if g[2] > 32]
+
+
+@pytest.mark.parametrize("row_tiles", [1, 4])
+@pytest.mark.parametrize("geom", WIDE_GEOMS, ids=lambda g: "{}c{}-{}k{}x{}s{}x{}_{}x{}".format(
+    "t" if g[0] else "", g[1], g[2], g[3][0], g[3][1], g[4][0], g[4][1], g[8], g[9]))
+def test_row_tile_kernel_families(device, geom, row_tiles, monkeypatch):
+    """The library picks one row tile per wave for small grids and four otherwise; both families on the same
+    shapes (every test shape here is a small grid, so the default run alone would never reach the four-tile
+    kernels), with a concatenated second source on the transposed ones."""
+    import unet_amd.fused as fused
+    from unet_amd.fused import FusedConv
+    monkeypatch.setattr(fused, "ROW_TILES", row_tiles)
+    tr, cin, cout, k, s, p, op, d, H, W = geom
+    conv = (nn.ConvTranspose2d(cin, cout, k, s, p, output_padding=op, dilation=d) if tr
+            else nn.Conv2d(cin, cout, k, s, p, dilation=d))
+    seq = nn.Sequential(conv, nn.BatchNorm2d(cout), nn.LeakyReLU()).eval()
+    _fill(seq, 4321 + cin * 5 + cout)
+    x = _seeded((3, cin, H, W), 77 + W)
+    with torch.no_grad():
+        want = seq(x)
+    seq.to(device)
+    f = FusedConv(seq[0], seq[1], seq[2])
+    if tr and cin >= 4:
+        c0 = cin // 2 if (cin // 2) % 2 == 0 else cin // 2 + 1
+        got = f(x[:, :c0].contiguous().to(device), x[:, c0:].contiguous().to(device))
+    else:
+        got = f(x.to(device))
+    assert_close(got, want, what="row_tiles={}".format(row_tiles))
+    seq.cpu()
+
+
+def test_row_tile_request_is_validated(device):
+    import unet_amd.fused as fused
+    from unet_amd import _lib
+    from unet_amd.fused import FusedConv
+    conv = nn.Conv2d(4, 64, (5, 3), (2, 1), (2, 1)).to(device).eval()
+    x = torch.zeros(1, 4, 9, 16, device=device)
+    try:
+        fused.ROW_TILES = 3
+        with pytest.raises(_lib.UnetmiError):
+            FusedConv(conv)(x)
+    finally:
+        fused.ROW_TILES = 0
+
+
 ACTS = [nn.LeakyReLU(), nn.PReLU(), nn.PReLU(12), nn.ReLU(), nn.SiLU(), nn.Softplus(), nn.Sigmoid(),
         nn.Tanh(), nn.GELU(), nn.Identity()]
 

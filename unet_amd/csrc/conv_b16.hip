@@ -30,6 +30,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <type_traits>
 
 #include "../../include/unetmi.h"
 #include "io_types.hpp"
@@ -48,7 +49,8 @@ __device__ __forceinline__ unsigned b16_pack2(float lo, float hi) {        // v_
 }
 
 #ifndef B16_ABLATE
-#define B16_ABLATE 0      // build-time experiment switches (tools/b16_probe.py); 0 in the shipped library
+#define B16_ABLATE 0      // build-time experiment switches (tools/b16_probe.py); 0 in the shipped library:
+                          // 1 no MFMA loop, 2 no operand DMA after the prologue, 4 no epilogue, 8 no step barrier, 16 no LDS reads
 #endif
 constexpr int kB16MaxPhase = 4;
 constexpr int kB16Waves = 8;          // waves (= output rows) per workgroup
@@ -96,6 +98,35 @@ __device__ __forceinline__ float b16_act_general(float v, int act, float slope) 
         case UNETMI_ACT_GELU:     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         default:                  return v >= 0.f ? v : v * slope;
     }
+}
+
+// f(integral_constant<int, I>) for I = FROM .. TO-1 with I a compile-time value
+template <int FROM, int TO, class F>
+__device__ __forceinline__ void static_for_b16(F&& f) {
+    if constexpr (FROM < TO) {
+        f(std::integral_constant<int, FROM>{});
+        static_for_b16<FROM + 1, TO>(f);
+    }
+}
+
+// LDS byte address of a pointer into the workgroup's shared memory
+__device__ __forceinline__ int b16_lds_addr(const void* q) {
+    return (int)(unsigned)(size_t)(__attribute__((address_space(3))) const char*)q;
+}
+// 16 bytes from LDS at (per-lane base) + (wave-uniform offset) + (immediate)
+__device__ __forceinline__ bf16x8 b16_lds_ld(int lane_base, int uniform, int imm) {
+    typedef const __attribute__((address_space(3))) bf16x8* lds_cv8;
+    if (B16_ABLATE & 16) {                       // timing experiment: operands without LDS reads
+        bf16x8 v;
+        asm volatile("" : "=v"(v) : "s"(uniform));
+        return v;
+    }
+    return *reinterpret_cast<lds_cv8>(static_cast<unsigned>(lane_base + uniform) + static_cast<unsigned>(imm));
+}
+// a wave-uniform value, kept in a scalar register and hidden from the optimizer's induction-variable rewriting
+__device__ __forceinline__ int b16_keep_scalar(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
 }
 
 // wait until at most n of this wave's vector-memory operations (LDS-DMA included) are outstanding
@@ -331,64 +362,115 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
         colb[nt] = ((PAIR ? j : nt * 32 + j) * p.siw + p.ph[a].offw[PAIR ? nt : 0] - wbase) * 16;
-    const int a_lane = half * 512 + j * 16;
+    // per-lane LDS byte addresses: this lane's slot of a weight operand, and its pixel of an input image's first row
+    const int la = b16_lds_addr(s_w) + half * 512 + j * 16;
+    int lb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) lb[nt] = b16_lds_addr(s_in) + half * plane * 16 + colb[nt];
 
     int s = 0;
     for (int g = 0; g < G; ++g) {
-        const char* in_img = s_in + (g % nin_buf) * p.in_buf_bytes;
         for (int sub = 0; sub < nsub; ++sub, ++s) {
             const int tc = sub % nchunk;
             int issued = (B16_ABLATE & 2) ? 0 : issue_weights(s + p.wring - 1);
             if (sub == 0 && !(B16_ABLATE & 2)) issued += issue_input(g + p.din);
 
-            const char* wimg = s_w + (s % p.wring) * p.w_buf_bytes + a_lane;
-            for (int tr = 0; tr < R; ++tr) {
-                const int th = tc * R + tr;
-                const int rowl = wave * p.sih + th * p.tdh - negh;
-                const char* brow = in_img + (half * plane + rowl * cols_in) * 16;
-                if constexpr (PAIR) {
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const int ntw_n = nt ? ntw1 : ntw0;
-                        const char* wt0 = wimg + (tr * ntws + (nt ? ntw0 : 0)) * MT * 1024;
-#pragma unroll 1
-                        for (int tw = 0; tw < ((B16_ABLATE & 1) ? 0 : ntw_n); ++tw) {
-                            const bf16x8 B = *reinterpret_cast<const bf16x8*>(brow + colb[nt] + tw * p.tdw * 16);
-                            const char* wt = wt0 + tw * MT * 1024;
+            // The operand reads of a step are software-pipelined inside each wave: the sequence of weight operands
+            // (tap, mt) alternates between two register sets, each read issued one MFMA group before its use, and
+            // the pixel operands of the next tap are requested as soon as the last MFMA group of the current tap has
+            // issued -- a wave that waited for every ds_read_b128 in front of the MFMAs that use it spent more time
+            // on the ~15 exposed LDS round trips of a step than on the step's MFMAs.
+            // An LDS address is (per-lane base) + (wave-uniform offset): the uniform offsets are kept opaque to the
+            // optimizer (b16_keep_scalar), which otherwise strength-reduces the tap walk into a dozen live per-lane
+            // pointers and spills the DMA offsets to make room for them.
+            int uw = b16_keep_scalar((s % p.wring) * p.w_buf_bytes);                        // weights of the next A read
+            const int rowl0 = wave * p.sih + tc * R * p.tdh - negh;
+            const int ub0 = (g % nin_buf) * p.in_buf_bytes + rowl0 * cols_in * 16;         // tap (row 0, column 0)
+            const int tdw16 = p.tdw * 16, rowstep = p.tdh * cols_in * 16;
+            if constexpr (PAIR) {
+                // a segment = the taps of one column phase in one tap row; nt is compile-time (it names accumulators)
+                for (int tr = 0; tr < ((B16_ABLATE & 1) ? 0 : R); ++tr) {
+                    static_for_b16<0, 2>([&](auto nt_tag) {
+                        constexpr int nt = decltype(nt_tag)::value;
+                        const int cnt = nt ? ntw1 : ntw0;
+                        int ub = b16_keep_scalar(ub0 + tr * rowstep);
+                        bf16x8 A[2], B = b16_lds_ld(lb[nt], ub, 0);
+                        A[0] = b16_lds_ld(la, uw, 0);
+                        auto tap = [&](auto par_tag, bool more) {
+                            constexpr int PAR = decltype(par_tag)::value;
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt) {
-                                const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[mt][nt], 0, 0, 0);
+                                const int cur = (PAR + mt) & 1;
+                                if (mt + 1 < MT) A[cur ^ 1] = b16_lds_ld(la, uw, (mt + 1) * 1024);
+                                else if (more) A[cur ^ 1] = b16_lds_ld(la, uw, MT * 1024);
+                                __builtin_amdgcn_sched_barrier(0);      // the read goes out BEFORE the MFMAs it hides under
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur], B, acc[mt][nt], 0, 0, 0);
                             }
+                            uw = b16_keep_scalar(uw + MT * 1024);
+                            ub = b16_keep_scalar(ub + tdw16);
+                            if (more) B = b16_lds_ld(lb[nt], ub, 0);
+                        };
+                        int u = 0;
+                        for (; u + 1 < cnt; u += 2) {
+                            tap(std::integral_constant<int, 0>{}, true);
+                            tap(std::integral_constant<int, (MT & 1)>{}, u + 2 < cnt);
                         }
-                    }
-                } else {
-#pragma unroll 1
-                    for (int tw = 0; tw < ((B16_ABLATE & 1) ? 0 : ntw0); ++tw) {
-                        bf16x8 B[NT];
+                        if (u < cnt) tap(std::integral_constant<int, 0>{}, false);
+                    });
+                }
+            } else {
+                const int T = (B16_ABLATE & 1) ? 0 : R * ntw0;      // taps of this step, row-major
+                if (T > 0) {
+                    int ub = b16_keep_scalar(ub0), twn = 0;         // pixel operands and tap column of the NEXT B read
+                    auto next_ub = [&]() {
+                        int nb = ub + tdw16;
+                        if (++twn == ntw0) { twn = 0; nb += rowstep - ntw0 * tdw16; }
+                        ub = b16_keep_scalar(nb);
+                    };
+                    bf16x8 A[2], B[NT];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            B[nt] = *reinterpret_cast<const bf16x8*>(brow + colb[nt] + tw * p.tdw * 16);
-                        const char* wt = wimg + (tr * ntws + tw) * MT * 1024;
+                    for (int nt = 0; nt < NT; ++nt) B[nt] = b16_lds_ld(lb[nt], ub, 0);
+                    A[0] = b16_lds_ld(la, uw, 0);
+                    next_ub();
+                    auto tap = [&](auto par_tag, bool more) {
+                        constexpr int PAR = decltype(par_tag)::value;
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            const bf16x8 A = *reinterpret_cast<const bf16x8*>(wt + mt * 1024);
+                            const int cur = (PAR + mt) & 1;
+                            if (mt + 1 < MT) A[cur ^ 1] = b16_lds_ld(la, uw, (mt + 1) * 1024);
+                            else if (more) A[cur ^ 1] = b16_lds_ld(la, uw, MT * 1024);
+                            __builtin_amdgcn_sched_barrier(0);          // the read goes out BEFORE the MFMAs it hides under
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[nt], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur], B[nt], acc[mt][nt], 0, 0, 0);
                         }
+                        if (more) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) B[nt] = b16_lds_ld(lb[nt], ub, 0);
+                        }
+                        uw = b16_keep_scalar(uw + MT * 1024);
+                        next_ub();
+                    };
+                    int u = 0;
+                    for (; u + 1 < T; u += 2) {
+                        tap(std::integral_constant<int, 0>{}, true);
+                        tap(std::integral_constant<int, (MT & 1)>{}, u + 2 < T);
                     }
+                    if (u < T) tap(std::integral_constant<int, 0>{}, false);
                 }
             }
             // everything issued before this step has to have landed; this step's own loads may fly on
-            b16_wait_vm(p.wring == 3 ? __builtin_amdgcn_readfirstlane(issued) : 0);
-            __builtin_amdgcn_s_barrier();
+            if (!(B16_ABLATE & 8)) {
+                b16_wait_vm(p.wring == 3 ? __builtin_amdgcn_readfirstlane(issued) : 0);
+                __builtin_amdgcn_s_barrier();
+            }
             asm volatile("" ::: "memory");
         }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
     const int i = i0 + wave;
+    if ((B16_ABLATE & 4) && p.N >= 0) return;           // timing experiment: no epilogue
     if (i >= prow) return;                              // wave-uniform
     const int oh = i * p.soh + p.ph[a].poh;
     b16_epilogue<MT, NT, GEN, PAIR>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
@@ -586,7 +668,7 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         if (occ2 && general_act) continue;
         const size_t ib = in_bytes(nt);
         const int din = (occ2 || shallow) ? 1 : (single_step_group ? 2 : 1);
-        const int wring = (occ2 || shallow) ? 2 : 3;
+        const int wring = (occ2 || shallow) ? 2 : 3;   // (a ring of 3 with two workgroups per CU was measured: no gain)
         const size_t lds = (size_t)(din + 1) * ib + (size_t)wring * a.w_buf_bytes + par_bytes;
         const bool fits = occ2 ? (lds <= 81856 && ib <= (size_t)kB16MaxQ / 2 * kB16Waves * 1024)
                                : (lds <= 160 * 1024 && ib <= (size_t)kB16MaxQ * kB16Waves * 1024);

@@ -4,14 +4,22 @@
 
 namespace unetmi {
 
-bool launch_conv_ng2(int wn, int ntw0, int ntw1, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p) {
+bool launch_conv_ng2(int wn, int ntw0, int ntw1, int tpg, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p) {
 #define UNETMI_NG2(WN_, A_, B_)                                                             \
-    if (wn == WN_ && ntw0 == A_ && ntw1 == B_) {                                            \
+    if (wn == WN_ && ntw0 == A_ && ntw1 == B_ && tpg == 4) {                                \
         launch_dma_variant<2, 4, 4 / WN_, WN_, A_, B_>(grid, lds, s, p);             \
         return true;                                                                        \
     }
     UNETMI_NG2(2, 1, 2) UNETMI_NG2(2, 3, 2) UNETMI_NG2(1, 1, 2) UNETMI_NG2(1, 3, 2)
 #undef UNETMI_NG2
+    // one row tile per wave (small grids; conv_one_row_tile_built names exactly these)
+#define UNETMI_NG2_T1(A_, B_)                                                               \
+    if (wn == 2 && ntw0 == A_ && ntw1 == B_ && tpg == 1) {                                  \
+        launch_dma_variant<2, 1, 2, 2, A_, B_>(grid, lds, s, p);                            \
+        return true;                                                                        \
+    }
+    UNETMI_NG2_T1(1, 2) UNETMI_NG2_T1(3, 2)
+#undef UNETMI_NG2_T1
     return false;
 }
 

@@ -583,7 +583,7 @@ inline void launch_conv_variant(unsigned grid, size_t lds, hipStream_t stream, c
 // Instantiation units.  Each returns false when it holds no kernel for the request.
 bool launch_conv_staged(int ng, int wn, bool two, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
 bool launch_conv_dma_generic(int ng, int wn, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
-bool launch_conv_ng1(int wn, int ntw0, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
-bool launch_conv_ng2(int wn, int ntw0, int ntw1, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
+bool launch_conv_ng1(int wn, int ntw0, int tpg, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
+bool launch_conv_ng2(int wn, int ntw0, int ntw1, int tpg, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p);
 
 }  // namespace unetmi

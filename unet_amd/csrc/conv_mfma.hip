@@ -91,10 +91,10 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
     } else {
         const size_t lds = pl.lds_bytes_dma;
         if (pl.w.tap_step == 1) {          // unrolled tap rows with immediate LDS offsets
-            if (pl.NG == 1) done = launch_conv_ng1(pl.WN, pl.w.ntap[0], total, lds, stream, p);
-            else            done = launch_conv_ng2(pl.WN, pl.w.ntap[0], pl.w.ntap[1], total, lds, stream, p);
+            if (pl.NG == 1) done = launch_conv_ng1(pl.WN, pl.w.ntap[0], pl.TPG, total, lds, stream, p);
+            else            done = launch_conv_ng2(pl.WN, pl.w.ntap[0], pl.w.ntap[1], pl.TPG, total, lds, stream, p);
         }
-        if (!done) done = launch_conv_dma_generic(pl.NG, pl.WN, total, lds, stream, p);
+        if (!done && pl.TPG == 4) done = launch_conv_dma_generic(pl.NG, pl.WN, total, lds, stream, p);
     }
     if (!done) return hipErrorInvalidConfiguration;
     return hipGetLastError();

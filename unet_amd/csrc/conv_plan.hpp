@@ -97,6 +97,12 @@ struct ConvPlan {
     int direct_rpt = 8, direct_kt = 1, direct_kpad = 1, direct_pad = 0;
 };
 
+constexpr int kSmallGridWgs = 256;      // a grid of at most this many workgroups takes one row tile per wave
+
+struct ConvPlan;
+// kernels with one row tile per wave exist for the LDS-DMA kernels with unrolled tap rows, 64-channel blocks
+inline bool conv_one_row_tile_built(const UnetmiConvDesc& d, const ConvPlan& pl);
+
 // Thin layers go to the direct kernel: kernel width 1, unit stride and dilation,
 // height 1/3/7, and either <= 2 output channels or (<= 32 outputs from <= 16 inputs).
 inline bool plan_direct(const UnetmiConvDesc& d, ConvPlan* pl) {
@@ -111,6 +117,14 @@ inline bool plan_direct(const UnetmiConvDesc& d, ConvPlan* pl) {
     if (pl->direct_pad < 0) return false;
     pl->direct = true;
     return true;
+}
+
+inline bool conv_one_row_tile_built(const UnetmiConvDesc& d, const ConvPlan& pl) {
+    if (d.reserved[0] == UNETMI_DTYPE_BF16 || d.in_mode == UNETMI_IN_ADD) return false;    // register-staged kernels
+    if (pl.w.tap_step != 1 || pl.WN != 2) return false;
+    const int t0 = pl.w.ntap[0], t1 = pl.w.ntap[1];
+    if (pl.NG == 1) return t0 == 1 || t0 == 3 || t0 == 5 || t0 == 7;
+    return t1 == 2 && (t0 == 1 || t0 == 3);
 }
 
 inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
@@ -212,6 +226,26 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     for (int g = 0; g < pl->w.nphase; ++g) max_nj = std::max(max_nj, pl->w.nout[g]);
     pl->njt = (max_nj + kTileJ - 1) / kTileJ;
     for (int a = 0; a < pl->h.nphase; ++a) pl->nit[a] = (pl->h.nout[a] + pl->TI - 1) / pl->TI;
+
+    // Small grids (the deep 3x32 ... 9x64 maps): with at most one workgroup per CU a launch lasts as long as ONE
+    // wave's serial walk over all channels and taps with its four row tiles, whatever the FLOP count.  One row
+    // tile per wave (two output rows per workgroup) gives four times the workgroups and a quarter of that chain.
+    // The channel chunking -- and with it the packed weight image -- stays as computed above for four row tiles,
+    // so one packed image serves every batch size.
+    long long wgs = 0;
+    for (int a = 0; a < pl->h.nphase; ++a) wgs += (long long)pl->nit[a] * pl->njt * d.N * pl->nco_blk;
+    // reserved[1] of the descriptor: 0 = decide from the grid, 4 = four row tiles, 1 = one row tile where built
+    const bool one_tile = d.reserved[1] == 1 || (d.reserved[1] == 0 && wgs <= kSmallGridWgs);
+    if (one_tile && conv_one_row_tile_built(d, *pl)) {
+        pl->TPG = 1;
+        pl->TI = pl->WM;
+        pl->nrows = (pl->TI - 1) * pl->h.in_step + std::max(max_nth - 1, 0) * pl->h.tap_step + 1;
+        pl->plane = pl->nrows * pl->pitch;
+        pl->in_tile_floats = in_floats(pairs);
+        pl->lds_bytes = (size_t)(pl->in_tile_floats + pl->w_tile_floats + 5 * pl->NB) * 4;
+        pl->lds_bytes_dma = (size_t)(2 * (pl->in_tile_floats + pl->w_tile_floats) + 5 * pl->NB) * 4;
+        for (int a = 0; a < pl->h.nphase; ++a) pl->nit[a] = (pl->h.nout[a] + pl->TI - 1) / pl->TI;
+    }
     return true;
 }
 

@@ -243,6 +243,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dw[(size_t)ab * ntaps + tap] = s;
 }
 
+// The same sum when there are many splits and few outputs (the thin and the deep layers): one thread per output
+// walks `splits` dependent-latency loads, ~100 us for a thousand of them.  Here 16 lanes share an output -- lane q
+// sums splits q, q+16, ... (four loads in flight), and the 16 partial sums are added in index order -- so the
+// result is still a fixed-order sum, just a different fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                int splits, int ntaps, int A, int B) {
+    __shared__ float part[16][17];
+    const int il = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int total = ntaps * A * B;
+    const int i = blockIdx.x * 16 + il;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < total) {
+        int k = q;
+        for (; k + 48 < splits; k += 64) {
+            s0 += ws[(size_t)k * total + i];
+            s1 += ws[(size_t)(k + 16) * total + i];
+            s2 += ws[(size_t)(k + 32) * total + i];
+            s3 += ws[(size_t)(k + 48) * total + i];
+        }
+        for (; k < splits; k += 16) s0 += ws[(size_t)k * total + i];
+    }
+    part[q][il] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && i < total) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += part[r][il];
+        const int tap = i / (A * B), ab = i - tap * (A * B);
+        dw[(size_t)ab * ntaps + tap] = s;
+    }
+}
+
 struct WgradPlan {
     WgradArgs a;
     int NT, splits, bgroups, ablocks;
@@ -369,8 +401,13 @@ int unetmi_conv2d_wgrad(const UnetmiConvDesc* d, const float* in0, const float* 
     }
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("conv2d_wgrad launch: ") + hipGetErrorString(e));
     const int total = pl.a.ntaps * pl.a.A * pl.a.B;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.a.ws, dweight, pl.splits,
-                       pl.a.ntaps, pl.a.A, pl.a.B);
+    // one thread per output is a chain of `splits` load latencies: with many splits, 16 lanes share an output
+    if (pl.splits >= 32)
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((total + 15) / 16), dim3(256), 0, s, pl.a.ws, dweight, pl.splits,
+                           pl.a.ntaps, pl.a.A, pl.a.B);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, pl.a.ws, dweight, pl.splits,
+                           pl.a.ntaps, pl.a.A, pl.a.B);
     e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("conv2d_wgrad reduce launch: ") + hipGetErrorString(e));
 }

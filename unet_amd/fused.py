@@ -15,6 +15,11 @@ from . import _lib
 from .ops import conv2d_fwd, pack_conv_weights, pwconv64
 
 
+# Row tiles per wave requested from the MFMA convolution kernels (reserved[1] of the descriptor): 0 lets the
+# library choose from the grid size; tests set 1 or 4 to run one kernel family on every shape.
+ROW_TILES = 0
+
+
 def _pair(v):
     if isinstance(v, (tuple, list)):
         if len(v) == 1:
@@ -213,7 +218,7 @@ class FusedConv:
             try:
                 return conv2d_fwd(x, x2, wimg, st["bias"], st["scale"], st["shift"],
                                   st["act_param"], gate, residual, st["geom"],
-                                  [st["transposed"], mode, st["act"], int(self.act_first)])
+                                  [st["transposed"], mode, st["act"], int(self.act_first), ROW_TILES])
             except _lib.UnetmiError as e:
                 if e.code != _lib.E_UNSUPPORTED or (x2 is None and x.dtype == torch.float32):
                     raise
@@ -228,7 +233,7 @@ class FusedConv:
             merged = torch.cat([x, x2], dim=1) if mode == _lib.IN_CONCAT else x + x2
             return conv2d_fwd(merged, None, st["wpacked"], st["bias"], st["scale"], st["shift"],
                               st["act_param"], gate, residual, st["geom"],
-                              [st["transposed"], _lib.IN_SINGLE, st["act"], int(self.act_first)])
+                              [st["transposed"], _lib.IN_SINGLE, st["act"], int(self.act_first), ROW_TILES])
         ones = torch.ones_like(st["bias"])
         return conv2d_fwd(x, x2, wimg, st["bias"], ones, torch.zeros_like(ones), None, gate,
-                          residual, st["geom"], [st["transposed"], mode, _lib.ACT_NONE, 0])
+                          residual, st["geom"], [st["transposed"], mode, _lib.ACT_NONE, 0, ROW_TILES])

@@ -39,7 +39,7 @@ def dtype_code(t):
 
 def make_desc(N, C0, C1, H, W, geom, flags, act_pc=0, has_gate=0, has_residual=0, dtype=0):
     K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
-    transposed, in_mode, act, act_first = flags
+    transposed, in_mode, act, act_first = flags[:4]     # optional fifth entry: row tiles per wave (0 | 1 | 4)
     d = ConvDesc()
     d.N, d.C0, d.C1, d.H, d.W, d.K = N, C0, C1, H, W, K
     d.OH = conv_out_size(H, kh, sh, ph, dh, oph, transposed)
@@ -48,13 +48,14 @@ def make_desc(N, C0, C1, H, W, geom, flags, act_pc=0, has_gate=0, has_residual=0
     d.transposed, d.in_mode, d.act, d.act_first = transposed, in_mode, act, act_first
     d.act_param_per_channel, d.has_gate, d.has_residual = act_pc, has_gate, has_residual
     d.reserved[0] = dtype
+    d.reserved[1] = flags[4] if len(flags) > 4 else 0
     return d
 
 
 def pack_conv_weights(weight, C0, C1, geom, flags):
     """Host-side repack of a torch-layout weight into the kernel's image
     (unetmi_conv2d_pack_weights).  Returns a CPU float32 tensor."""
-    flags = list(flags)
+    flags = list(flags)[:4]
     flags[1] = _lib.IN_CONCAT if C1 else _lib.IN_SINGLE
     d = make_desc(1, C0, C1, 64, 64, geom, flags)
     # H/W do not enter the image; give the descriptor any consistent sizes
