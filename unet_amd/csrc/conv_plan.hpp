@@ -241,6 +241,20 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
         pl->TI = pl->WM;
         pl->nrows = (pl->TI - 1) * pl->h.in_step + std::max(max_nth - 1, 0) * pl->h.tap_step + 1;
         pl->plane = pl->nrows * pl->pitch;
+        // A chunk of such a workgroup is a few hundred MFMAs, shorter than the round trip of the next chunk's
+        // DMA, so the launch would last (chunks x round trip).  Merge k consecutive chunks while both LDS images
+        // stay within 80 KB: with one column phase the weight image is contiguous in channel pairs, so it does not
+        // change as long as k divides the chunk count of each source (with two column phases a chunk holds phase
+        // 0's pairs and then phase 1's, so those layers keep their chunks).
+        for (int k = pl->w.nphase == 1 ? 8 : 0; k >= 2; k /= 2) {
+            const int n1 = pl->nchunk - pl->nchunk0;
+            if (pl->nchunk0 % k || n1 % k) continue;
+            if ((size_t)(2 * (in_floats(pairs * k) + w_floats(pairs * k)) + 5 * pl->NB) * 4 > 80 * 1024) continue;
+            pairs *= k;
+            pl->ci_chunk = 2 * pairs; pl->nchunk0 /= k; pl->nchunk /= k;
+            pl->w_tile_floats = w_floats(pairs);
+            break;
+        }
         pl->in_tile_floats = in_floats(pairs);
         pl->lds_bytes = (size_t)(pl->in_tile_floats + pl->w_tile_floats + 5 * pl->NB) * 4;
         pl->lds_bytes_dma = (size_t)(2 * (pl->in_tile_floats + pl->w_tile_floats) + 5 * pl->NB) * 4;
