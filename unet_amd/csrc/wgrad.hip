@@ -185,19 +185,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
                 load_p(p + 1);
                 load_q(ynew);
             }
+            // Operands of a 4-pixel group are read one group ahead into a second register set: this kernel runs one
+            // wave per SIMD, so a read that is waited for right where it is issued (what the compiler makes of the
+            // plain loop: one lgkmcnt(0) per four MFMAs) leaves the matrix pipe idle for the whole LDS round trip.
             const float* tp = sP + buf * 64 * kPPitch + la;
+            float av[2][4], bv[2][NT];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[0][t] = tp[t * 16 * kPPitch];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[0][j] = sQ[rowoff[j]];
 #pragma unroll
             for (int gq = 0; gq < kTQ / 4; ++gq) {
-                float av[4];
+                const int cur = gq & 1, nxt = cur ^ 1;
+                if (gq + 1 < kTQ / 4) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) av[t] = tp[t * 16 * kPPitch + gq * 4];
+                    for (int t = 0; t < 4; ++t) av[nxt][t] = tp[t * 16 * kPPitch + (gq + 1) * 4];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bv[nxt][j] = sQ[rowoff[j] + (gq + 1) * 4 * g.sw];
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    const float bv = sQ[rowoff[j] + gq * 4 * g.sw];
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[j][t], 0, 0, 0);
+                        acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][t], bv[cur][j], acc[j][t], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (more) {
                 store_p(buf ^ 1);
