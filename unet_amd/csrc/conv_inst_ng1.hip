@@ -13,10 +13,14 @@ bool launch_conv_ng1(int wn, int ntw0, int tpg, unsigned grid, size_t lds, hipSt
     UNETMI_NG1(2, 1) UNETMI_NG1(2, 3) UNETMI_NG1(2, 5) UNETMI_NG1(2, 7)
     UNETMI_NG1(1, 1) UNETMI_NG1(1, 3) UNETMI_NG1(1, 5) UNETMI_NG1(1, 7)
 #undef UNETMI_NG1
-    // one row tile per wave (small grids; conv_one_row_tile_built names exactly these)
+    // one or two row tiles per wave (small and mid-sized grids; conv_one_row_tile_built names exactly these)
 #define UNETMI_NG1_T1(NTW_)                                                                 \
     if (wn == 2 && ntw0 == NTW_ && tpg == 1) {                                              \
         launch_dma_variant<1, 1, 2, 2, NTW_, 0>(grid, lds, s, p);                           \
+        return true;                                                                        \
+    }                                                                                       \
+    if (wn == 2 && ntw0 == NTW_ && tpg == 2) {                                              \
+        launch_dma_variant<1, 2, 2, 2, NTW_, 0>(grid, lds, s, p);                           \
         return true;                                                                        \
     }
     UNETMI_NG1_T1(1) UNETMI_NG1_T1(3) UNETMI_NG1_T1(5) UNETMI_NG1_T1(7)

@@ -12,10 +12,14 @@ bool launch_conv_ng2(int wn, int ntw0, int ntw1, int tpg, unsigned grid, size_t 
     }
     UNETMI_NG2(2, 1, 2) UNETMI_NG2(2, 3, 2) UNETMI_NG2(1, 1, 2) UNETMI_NG2(1, 3, 2)
 #undef UNETMI_NG2
-    // one row tile per wave (small grids; conv_one_row_tile_built names exactly these)
+    // one or two row tiles per wave (small and mid-sized grids; conv_one_row_tile_built names exactly these)
 #define UNETMI_NG2_T1(A_, B_)                                                               \
     if (wn == 2 && ntw0 == A_ && ntw1 == B_ && tpg == 1) {                                  \
         launch_dma_variant<2, 1, 2, 2, A_, B_>(grid, lds, s, p);                            \
+        return true;                                                                        \
+    }                                                                                       \
+    if (wn == 2 && ntw0 == A_ && ntw1 == B_ && tpg == 2) {                                  \
+        launch_dma_variant<2, 2, 2, 2, A_, B_>(grid, lds, s, p);                            \
         return true;                                                                        \
     }
     UNETMI_NG2_T1(1, 2) UNETMI_NG2_T1(3, 2)

@@ -100,7 +100,7 @@ struct ConvPlan {
 constexpr int kSmallGridWgs = 256;      // a grid of at most this many workgroups takes one row tile per wave
 
 struct ConvPlan;
-// kernels with one row tile per wave exist for the LDS-DMA kernels with unrolled tap rows, 64-channel blocks
+// kernels with one or two row tiles per wave exist for the LDS-DMA kernels with unrolled tap rows, 64-channel blocks
 inline bool conv_one_row_tile_built(const UnetmiConvDesc& d, const ConvPlan& pl);
 
 // Thin layers go to the direct kernel: kernel width 1, unit stride and dilation,
@@ -227,26 +227,44 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     pl->njt = (max_nj + kTileJ - 1) / kTileJ;
     for (int a = 0; a < pl->h.nphase; ++a) pl->nit[a] = (pl->h.nout[a] + pl->TI - 1) / pl->TI;
 
-    // Small grids (the deep 3x32 ... 9x64 maps): with at most one workgroup per CU a launch lasts as long as ONE
-    // wave's serial walk over all channels and taps with its four row tiles, whatever the FLOP count.  One row
-    // tile per wave (two output rows per workgroup) gives four times the workgroups and a quarter of that chain.
+    // Row tiles per wave.  Small grids (the deep 3x32 ... 9x64 maps): with at most one workgroup per CU a launch
+    // lasts as long as ONE wave's serial walk over all channels and taps with its four row tiles, whatever the FLOP
+    // count.  One row tile per wave (two output rows per workgroup) gives four times the workgroups and a quarter
+    // of that chain.
     // The channel chunking -- and with it the packed weight image -- stays as computed above for four row tiles,
     // so one packed image serves every batch size.
     long long wgs = 0;
     for (int a = 0; a < pl->h.nphase; ++a) wgs += (long long)pl->nit[a] * pl->njt * d.N * pl->nco_blk;
-    // reserved[1] of the descriptor: 0 = decide from the grid, 4 = four row tiles, 1 = one row tile where built
-    const bool one_tile = d.reserved[1] == 1 || (d.reserved[1] == 0 && wgs <= kSmallGridWgs);
-    if (one_tile && conv_one_row_tile_built(d, *pl)) {
-        pl->TPG = 1;
-        pl->TI = pl->WM;
+    // reserved[1] of the descriptor: 0 = decide from the grid, 4 / 2 / 1 = that many row tiles where built.
+    // Mid-sized grids: the launch takes ceil(workgroups / resident slots) rounds, so 1.4 rounds of work cost 2;
+    // two row tiles per wave halve the granule (at ~8 % more LDS reads and weight traffic per FLOP) and are taken
+    // when that saves more than it costs.
+    const bool built = conv_one_row_tile_built(d, *pl);
+    int tpg = 4;
+    if (built && d.reserved[1] == 1) tpg = 1;
+    else if (built && d.reserved[1] == 2) tpg = 2;
+    else if (built && d.reserved[1] == 0) {
+        if (wgs <= kSmallGridWgs) tpg = 1;
+        else {
+            const long long slots = (pl->NG == 1 ? 3 : 2) * 256;          // resident workgroups of the chip
+            long long wgs2 = 0;
+            for (int a = 0; a < pl->h.nphase; ++a)
+                wgs2 += (long long)((pl->h.nout[a] + 2 * pl->WM - 1) / (2 * pl->WM)) * pl->njt * d.N * pl->nco_blk;
+            const long long r4 = (wgs + slots - 1) / slots, r2 = (wgs2 + slots - 1) / slots;
+            if (r2 * 2 * 108 < r4 * 4 * 95) tpg = 2;
+        }
+    }
+    if (tpg != 4) {
+        pl->TPG = tpg;
+        pl->TI = pl->WM * tpg;
         pl->nrows = (pl->TI - 1) * pl->h.in_step + std::max(max_nth - 1, 0) * pl->h.tap_step + 1;
         pl->plane = pl->nrows * pl->pitch;
-        // A chunk of such a workgroup is a few hundred MFMAs, shorter than the round trip of the next chunk's
-        // DMA, so the launch would last (chunks x round trip).  Merge k consecutive chunks while both LDS images
-        // stay within 80 KB: with one column phase the weight image is contiguous in channel pairs, so it does not
-        // change as long as k divides the chunk count of each source (with two column phases a chunk holds phase
-        // 0's pairs and then phase 1's, so those layers keep their chunks).
-        for (int k = pl->w.nphase == 1 ? 8 : 0; k >= 2; k /= 2) {
+        // A chunk of a one-row-tile workgroup is a few hundred MFMAs, shorter than the round trip of the next
+        // chunk's DMA, so the launch would last (chunks x round trip).  Merge k consecutive chunks while both LDS
+        // images stay within 80 KB: with one column phase the weight image is contiguous in channel pairs, so it
+        // does not change as long as k divides the chunk count of each source (with two column phases a chunk
+        // holds phase 0's pairs and then phase 1's, so those layers keep their chunks).
+        for (int k = (tpg == 1 && pl->w.nphase == 1) ? 8 : 0; k >= 2; k /= 2) {
             const int n1 = pl->nchunk - pl->nchunk0;
             if (pl->nchunk0 % k || n1 % k) continue;
             if ((size_t)(2 * (in_floats(pairs * k) + w_floats(pairs * k)) + 5 * pl->NB) * 4 > 80 * 1024) continue;
