@@ -182,6 +182,18 @@ assert all(torch.equal(g, gathered[0]) for g in gathered)
 next(iter(net.parameters())).grad = None
 bucket.zero_grad()
 assert next(iter(net.parameters())).grad.data_ptr() == bucket.grad.data_ptr()
+# detach_grads / collect_grads: gradients gathered after the backward pass are those accumulated into the views
+shard = slice(rank * per, (rank + 1) * per)
+bucket.zero_grad()
+torch.mean((net(x[shard]) - target[shard]) ** 2).backward()
+accumulated = bucket.grad.clone()
+bucket.detach_grads()
+assert all(p.grad is None for p in net.parameters())
+torch.mean((net(x[shard]) - target[shard]) ** 2).backward()
+bucket.collect_grads()
+assert torch.equal(bucket.grad, accumulated)
+lo, hi = bucket.grad.data_ptr(), bucket.grad.data_ptr() + 4 * bucket.grad.numel()
+assert all(lo <= p.grad.data_ptr() < hi for p in net.parameters())
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
