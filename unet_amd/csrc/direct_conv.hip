@@ -78,10 +78,20 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectArgs p) {
     constexpr int EB = BF16 ? 2 : 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ow = blockIdx.x * 64 + lane;
-    const int oh0 = (blockIdx.y * 4 + wave) * RPT;
-    const int n = blockIdx.z / p.nkt;
-    const int k0 = (blockIdx.z % p.nkt) * KT;
+    // Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  Tile t of the
+    // (sample x output tile, row block, column strip) order -- strips fastest -- goes to the XCD whose contiguous
+    // eighth of the tiles holds it, so one XCD walks a contiguous range of tiles: the 128-byte
+    // lines that neighbouring 64-column strips share (rows of 509 floats are not line-aligned) and the halo rows
+    // that neighbouring row blocks share are then fetched, and partial lines merged, in ONE L2.
+    const unsigned tiles = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = lin & 7u, q = tiles >> 3, r = tiles & 7u;      // the first r XCDs walk q + 1 tiles, the rest q
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    const unsigned bx = t % gridDim.x, by = (t / gridDim.x) % gridDim.y, bz = t / (gridDim.x * gridDim.y);
+    const int ow = bx * 64 + lane;
+    const int oh0 = (by * 4 + wave) * RPT;
+    const int n = bz / p.nkt;
+    const int k0 = (bz % p.nkt) * KT;
     if (oh0 >= p.OH) return;                       // wave-uniform
     const bool col_ok = ow < p.W;
     const int HW = p.H * p.W;
