@@ -9,6 +9,7 @@
 #include <string>
 
 #include "../../include/unetmi.h"
+#include "io_types.hpp"
 
 namespace unetmi {
 
@@ -18,10 +19,10 @@ __device__ __forceinline__ float act_value(int act, float u, float p) {
     switch (act) {
         case UNETMI_ACT_LEAKY: return u >= 0.f ? u : p * u;
         case UNETMI_ACT_RELU: return u > 0.f ? u : 0.f;
-        case UNETMI_ACT_SILU: return u / (1.f + expf(-u));
-        case UNETMI_ACT_SOFTPLUS: return u > 20.f ? u : log1pf(expf(u));
-        case UNETMI_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
-        case UNETMI_ACT_TANH: return tanhf(u);
+        case UNETMI_ACT_SILU: return u * fast_sigmoid(u);
+        case UNETMI_ACT_SOFTPLUS: return fast_softplus(u);
+        case UNETMI_ACT_SIGMOID: return fast_sigmoid(u);
+        case UNETMI_ACT_TANH: return fast_tanh(u);
         case UNETMI_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
         default: return u;
     }

@@ -91,10 +91,10 @@ struct B16Args {
 // skipped code, and the instruction-cache misses of the skips cost more than the whole matrix loop.
 __device__ __forceinline__ float b16_act_general(float v, int act, float slope) {
     switch (act) {
-        case UNETMI_ACT_SILU:     return v / (1.f + expf(-v));
-        case UNETMI_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
-        case UNETMI_ACT_SIGMOID:  return 1.f / (1.f + expf(-v));
-        case UNETMI_ACT_TANH:     return tanhf(v);
+        case UNETMI_ACT_SILU:     return v * fast_sigmoid(v);
+        case UNETMI_ACT_SOFTPLUS: return fast_softplus(v);
+        case UNETMI_ACT_SIGMOID:  return fast_sigmoid(v);
+        case UNETMI_ACT_TANH:     return fast_tanh(v);
         case UNETMI_ACT_GELU:     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         default:                  return v >= 0.f ? v : v * slope;
     }

@@ -56,10 +56,10 @@ template <int ACT>
 __device__ __forceinline__ float apply_act(float v, float slope) {
     if constexpr (ACT == UNETMI_ACT_LEAKY)         return v >= 0.f ? v : v * slope;
     else if constexpr (ACT == UNETMI_ACT_RELU)     return fmaxf(v, 0.f);
-    else if constexpr (ACT == UNETMI_ACT_SILU)     return v / (1.f + expf(-v));
-    else if constexpr (ACT == UNETMI_ACT_SOFTPLUS) return v > 20.f ? v : log1pf(expf(v));
-    else if constexpr (ACT == UNETMI_ACT_SIGMOID)  return 1.f / (1.f + expf(-v));
-    else if constexpr (ACT == UNETMI_ACT_TANH)     return tanhf(v);
+    else if constexpr (ACT == UNETMI_ACT_SILU)     return v * fast_sigmoid(v);
+    else if constexpr (ACT == UNETMI_ACT_SOFTPLUS) return fast_softplus(v);
+    else if constexpr (ACT == UNETMI_ACT_SIGMOID)  return fast_sigmoid(v);
+    else if constexpr (ACT == UNETMI_ACT_TANH)     return fast_tanh(v);
     else if constexpr (ACT == UNETMI_ACT_GELU)     return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     else                                           return v;
 }

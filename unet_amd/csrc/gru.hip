@@ -18,6 +18,7 @@
 #include <string>
 
 #include "../../include/unetmi.h"
+#include "io_types.hpp"
 
 namespace unetmi {
 
@@ -37,7 +38,7 @@ struct GruArgs {
     int T, BP, nwg;
 };
 
-__device__ __forceinline__ float gru_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float gru_sigmoid(float x) { return fast_sigmoid(x); }
 
 // device-wide barrier over co-resident workgroups: own flag word per workgroup, wave 0 polls them all
 __device__ __forceinline__ bool gru_grid_barrier(unsigned* flags, int nwg, unsigned step, int* s_flag) {
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(const GruArgs a)
             for (int g = 0; g < 3; ++g)
                 gh[g] = bh[g] + ((s_p[0][g * 4 + cu][cb] + s_p[1][g * 4 + cu][cb]) + (s_p[2][g * 4 + cu][cb] + s_p[3][g * 4 + cu][cb]));
             const float r = gru_sigmoid(gxv[0] + gh[0]), z = gru_sigmoid(gxv[1] + gh[1]);
-            const float n = tanhf(gxv[2] + r * gh[2]);
+            const float n = fast_tanh(gxv[2] + r * gh[2]);
             h = (1.f - z) * n + z * h;
             __hip_atomic_store(&a.hfull[((size_t)(t + 1) * H + u0 + cu) * BP + cb], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -39,6 +39,20 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
     return (unsigned short)(u >> 16);
 }
 
+// Transcendental activations on the hardware's own exp / log / reciprocal instructions (each accurate to about one
+// unit in the last place) instead of the math library's sequences, which are 30-60 instructions each: per value that
+// is more work than a thin layer's multiply-adds, and in the recurrence kernels it sits on the critical path of every
+// time step.  Absolute error <= ~2e-7 (tanh and softplus lose RELATIVE accuracy only where their value is ~1e-7).
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float t = __expf(-2.f * fabsf(x));
+    return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), x);
+}
+__device__ __forceinline__ float fast_softplus(float x) {          // log(1 + e^x) = max(x, 0) + log1p(e^-|x|)
+    const float t = __expf(-fabsf(x));
+    return fmaxf(x, 0.f) + (t < 2e-4f ? t * (1.f - 0.5f * t) : __logf(1.f + t));
+}
+
 template <bool BF16>
 __device__ __forceinline__ float ld_act(const void* p, size_t i) {
     if (BF16) return bf16_bits_to_f32(static_cast<const unsigned short*>(p)[i]);

@@ -20,6 +20,7 @@
 #include <string>
 
 #include "../../include/unetmi.h"
+#include "io_types.hpp"
 
 namespace unetmi {
 
@@ -40,7 +41,7 @@ struct LstmArgs {
     int T, BP, nwg, H;     // H: the real hidden size (gx and wrec rows are g*H + u)
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return fast_sigmoid(x); }
 
 // Device-wide barrier over the nwg co-resident workgroups, without a shared counter (same-address
 // atomics from 160 workgroups on 8 dies serialise at the memory side): every workgroup publishes the
@@ -140,9 +141,9 @@ __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs 
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 pre[g] = gxv[g] + ((s_p[0][g * 4 + cu][cb] + s_p[1][g * 4 + cu][cb]) + (s_p[2][g * 4 + cu][cb] + s_p[3][g * 4 + cu][cb]));
-            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = fast_tanh(pre[2]), og = sigmoidf_(pre[3]);
             c = fg * c + ig * gg;
-            __hip_atomic_store(&a.hfull[((size_t)(t + 1) * kLstmH + u0 + cu) * BP + cb], og * tanhf(c), __ATOMIC_RELAXED,
+            __hip_atomic_store(&a.hfull[((size_t)(t + 1) * kLstmH + u0 + cu) * BP + cb], og * fast_tanh(c), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
         if (!grid_barrier(a.sync, a.nwg, (unsigned)(t + 1), &s_flag)) break;

@@ -30,6 +30,7 @@
 #include <string>
 
 #include "../../include/unetmi.h"
+#include "io_types.hpp"
 
 namespace unetmi {
 
@@ -56,7 +57,7 @@ struct LstmXcdArgs {
     long long h_step, h_row;                  // element strides of hfull per step slot / per hidden unit
 };
 
-__device__ __forceinline__ float sigmoid_x(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_x(float x) { return fast_sigmoid(x); }
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {     // v + (v moved by the DPP control), within rows of 16 lanes
@@ -172,9 +173,9 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
                 pre[g] = gxv[g] + ((s_part[t & 1][0][0][0][idx] + s_part[t & 1][1][0][0][idx]) +
                                    (s_part[t & 1][2][0][0][idx] + s_part[t & 1][3][0][0][idx]));
             }
-            const float ig = sigmoid_x(pre[0]), fg = sigmoid_x(pre[1]), gg = tanhf(pre[2]), og = sigmoid_x(pre[3]);
+            const float ig = sigmoid_x(pre[0]), fg = sigmoid_x(pre[1]), gg = fast_tanh(pre[2]), og = sigmoid_x(pre[3]);
             c = fg * c + ig * gg;
-            const float hn = col_live ? og * tanhf(c) : 0.f;
+            const float hn = col_live ? og * fast_tanh(c) : 0.f;
             const unsigned long long granule =
                 (unsigned long long)__builtin_bit_cast(unsigned, hn) | ((unsigned long long)(unsigned)(t + 1) << 32);
             // written through the vector cache into the XCD's L2, which is where this XCD's readers look; the

@@ -123,10 +123,10 @@ __device__ __forceinline__ float in_act(int act, float u, float p) {
     switch (act) {
         case UNETMI_ACT_LEAKY: return u >= 0.f ? u : p * u;
         case UNETMI_ACT_RELU: return fmaxf(u, 0.f);
-        case UNETMI_ACT_SILU: return u / (1.f + expf(-u));
-        case UNETMI_ACT_SOFTPLUS: return u > 20.f ? u : log1pf(expf(u));
-        case UNETMI_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
-        case UNETMI_ACT_TANH: return tanhf(u);
+        case UNETMI_ACT_SILU: return u * fast_sigmoid(u);
+        case UNETMI_ACT_SOFTPLUS: return fast_softplus(u);
+        case UNETMI_ACT_SIGMOID: return fast_sigmoid(u);
+        case UNETMI_ACT_TANH: return fast_tanh(u);
         case UNETMI_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
         default: return u;
     }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void tanh_mask_kernel(const void* __restrict__
     if (i >= total) return;
     const size_t sp = i % HW, nk = i / HW;
     const size_t n = nk / K, k = nk % K;
-    st_act<BF16>(out, i, (tanhf(ld_act<BF16>(y, i)) + eps) * ld_act<BF16>(x, (n * Cx + k) * HW + sp));
+    st_act<BF16>(out, i, (fast_tanh(ld_act<BF16>(y, i)) + eps) * ld_act<BF16>(x, (n * Cx + k) * HW + sp));
 }
 
 // Gated-convolution epilogue: z[N,2K,HW] holds the feature conv in channels [0,K) and the mask conv's
@@ -184,10 +184,10 @@ __device__ __forceinline__ float glu_act(int act, float u, float p) {
     switch (act) {
         case UNETMI_ACT_LEAKY: return u >= 0.f ? u : p * u;
         case UNETMI_ACT_RELU: return fmaxf(u, 0.f);
-        case UNETMI_ACT_SILU: return u / (1.f + expf(-u));
-        case UNETMI_ACT_SOFTPLUS: return u > 20.f ? u : log1pf(expf(u));
-        case UNETMI_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
-        case UNETMI_ACT_TANH: return tanhf(u);
+        case UNETMI_ACT_SILU: return u * fast_sigmoid(u);
+        case UNETMI_ACT_SOFTPLUS: return fast_softplus(u);
+        case UNETMI_ACT_SIGMOID: return fast_sigmoid(u);
+        case UNETMI_ACT_TANH: return fast_tanh(u);
         case UNETMI_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
         default: return u;
     }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void glu_kernel(const void* __restrict__ z, co
         const int i = base + j * 256;
         if (i < HW) {
             const float c = ld_act<BF16>(z, c_off + i), m = ld_act<BF16>(z, m_off + i);
-            const float v = c * (1.f / (1.f + expf(-m)));
+            const float v = c * fast_sigmoid(m);
             st_act<BF16>(out, o_off + i, g * glu_act(act, fmaf(v, sc, sh), ap));
         }
     }
