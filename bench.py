@@ -89,26 +89,10 @@ def conv_macs(d):
 
 
 def kernel_variant(d):
-    """Name of the kernel instantiation that serves this layer, as rocprofv3 prints it
-    (mirrors the dispatch in unet_amd/csrc/conv_mfma.hip and conv_plan.hpp)."""
-    cin = d.C0 + (d.C1 if d.in_mode == 1 else 0)
-    if (d.kw == 1 and d.sw == 1 and d.sh == 1 and d.dh == 1 and d.kh in (1, 3, 7)
-            and (d.K <= 2 or (d.K <= 32 and cin * d.kh <= 112))):
-        rpt, kt = (8, d.K) if d.K <= 2 else (2, 16)
-        return "direct_conv_kernel<{}, {}, {}>".format(rpt, kt, d.kh)
-    ng = d.sw if d.transposed else 1
-    wn = 1 if d.K <= 32 else 2
-    if d.in_mode == 2:
-        return "conv_mfma_kernel<{}, 4, {}, {}, true, 0, 0>".format(ng, 4 // wn, wn)
-    ntw = (0, 0)
-    if d.dw == 1 or (d.transposed and d.sw == 2):
-        if ng == 1 and d.kw in (1, 3, 5, 7):
-            ntw = (d.kw, 0)
-        elif ng == 2:
-            taps = tuple(len([k for k in range(d.kw) if k % 2 == (b + d.pw) % 2]) for b in (0, 1))
-            if taps in ((1, 2), (3, 2)):
-                ntw = taps
-    return "conv_dma_kernel<{}, 4, {}, {}, {}, {}>".format(ng, 4 // wn, wn, ntw[0], ntw[1])
+    """Name of the kernel instantiation that serves this layer, as rocprofv3 prints it: asked of the library
+    (unetmi_conv2d_kernel_name), whose plan picks the instantiation from the geometry AND the grid size."""
+    from unet_amd.ops import conv_kernel_name
+    return conv_kernel_name(d)
 
 
 def measured_traffic(kernel):

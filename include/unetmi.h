@@ -118,6 +118,12 @@ void unetmi_last_error(char* buf, size_t n);
  * (0 on a bad descriptor).  The image depends on geometry only, not on N. */
 size_t unetmi_conv2d_packed_weight_bytes(const UnetmiConvDesc* d);
 
+/* HOST function, a measurement aid with no counterpart in the reference: the kernel instantiation
+ * unetmi_conv2d_fwd launches for this descriptor (it depends on N through the grid size), written as a profiler
+ * shows it without namespace, storage-type parameter and argument list, e.g. "conv_dma_kernel<1, 4, 2, 2, 5, 0>".
+ * bench.py labels its per-launch timings with it so that they can be matched against a rocprofv3 kernel trace. */
+int unetmi_conv2d_kernel_name(const UnetmiConvDesc* d, char* buf, size_t n);
+
 /* HOST function: rearranges a torch-layout weight tensor (host pointer,
  * contiguous fp32, [K,C,kh,kw] or [C,K,kh,kw] for transposed) into the
  * per-phase / per-channel-chunk image the kernel streams through LDS

@@ -20,6 +20,7 @@ EXPORTED_SYMBOLS = (
     "unetmi_version",
     "unetmi_last_error",
     "unetmi_conv2d_packed_weight_bytes",
+    "unetmi_conv2d_kernel_name",
     "unetmi_conv2d_pack_weights",
     "unetmi_conv2d_fwd",
     "unetmi_dwconv2d_fwd",
@@ -91,6 +92,8 @@ def _load():
     lib.unetmi_last_error.restype = None
     lib.unetmi_conv2d_packed_weight_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.unetmi_conv2d_packed_weight_bytes.restype = ctypes.c_size_t
+    lib.unetmi_conv2d_kernel_name.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_char_p, ctypes.c_size_t]
+    lib.unetmi_conv2d_kernel_name.restype = ctypes.c_int
     lib.unetmi_conv2d_pack_weights.argtypes = [ctypes.POINTER(ConvDesc), fp, fp]
     lib.unetmi_conv2d_pack_weights.restype = ctypes.c_int
     lib.unetmi_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 10 + [vp]

@@ -49,6 +49,31 @@ size_t unetmi_conv2d_packed_weight_bytes(const UnetmiConvDesc* d) {
     return pl.packed_floats * sizeof(float);
 }
 
+int unetmi_conv2d_kernel_name(const UnetmiConvDesc* d, char* buf, size_t n) {
+    if (!d || !buf || n == 0) return fail(UNETMI_E_BAD_ARG, "null argument to conv2d_kernel_name");
+    ConvPlan pl;
+    std::string err;
+    if (!make_plan(*d, &pl, &err)) return fail(UNETMI_E_BAD_DESC, err);
+    char name[96];
+    if (pl.direct) {
+        std::snprintf(name, sizeof(name), "direct_conv_kernel<%d, %d, %d>", pl.direct_rpt, pl.direct_kt, d->kh);
+    } else if (d->reserved[0] == UNETMI_DTYPE_BF16 || needs_two_loads(*d, pl)) {      // the register-staged kernel
+        std::snprintf(name, sizeof(name), "conv_mfma_kernel<%d, 4, %d, %d, %s, 0, 0>", pl.NG, pl.WM, pl.WN,
+                      needs_two_loads(*d, pl) ? "true" : "false");
+    } else {                                                  // same order of preference as launch_conv_mfma
+        int t0 = 0, t1 = 0;
+        if (pl.w.tap_step == 1) {
+            const int a = pl.w.ntap[0], b = pl.w.ntap[1];
+            if (pl.NG == 1 && (a == 1 || a == 3 || a == 5 || a == 7)) t0 = a;
+            else if (pl.NG == 2 && b == 2 && (a == 1 || a == 3)) { t0 = a; t1 = b; }
+        }
+        std::snprintf(name, sizeof(name), "conv_dma_kernel<%d, %d, %d, %d, %d, %d>", pl.NG, t0 ? pl.TPG : 4, pl.WM, pl.WN,
+                      t0, t1);
+    }
+    std::snprintf(buf, n, "%s", name);
+    return UNETMI_OK;
+}
+
 int unetmi_conv2d_pack_weights(const UnetmiConvDesc* d, const float* w, float* packed) {
     if (!d || !w || !packed) return fail(UNETMI_E_BAD_ARG, "null argument to pack_weights");
     ConvPlan pl;

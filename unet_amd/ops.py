@@ -72,6 +72,14 @@ def pack_conv_weights(weight, C0, C1, geom, flags):
     return packed
 
 
+def conv_kernel_name(desc):
+    """The kernel instantiation unetmi_conv2d_fwd launches for ``desc`` (unetmi_conv2d_kernel_name), as a profiler
+    prints it without namespace, storage-type parameter and argument list."""
+    buf = ctypes.create_string_buffer(128)
+    check(_lib.lib.unetmi_conv2d_kernel_name(ctypes.byref(desc), buf, len(buf)), "unetmi_conv2d_kernel_name")
+    return buf.value.decode()
+
+
 # Optional per-launch observer (bench.py's roofline leg): called as
 # fn(op_name, desc, start_event, end_event) with torch.cuda events recorded on
 # the launch stream immediately around the kernel.
