@@ -102,6 +102,12 @@ __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs 
     float c = 0.f;
     __syncthreads();
 
+    // this wave's weight operands do not change from step to step: they stay in registers for the whole sequence
+    // (re-read from LDS inside the step, each read was waited for in front of the MFMAs it feeds)
+    float av[kLstmKS];
+#pragma unroll
+    for (int ks = 0; ks < kLstmKS; ++ks) av[ks] = s_a[(wave * kLstmKS + ks) * 64 + lane];
+
     int t = 0;
     for (; t < a.T; ++t) {
         const float* hprev = a.hfull + (size_t)t * kLstmH * BP;
@@ -125,9 +131,8 @@ __global__ __launch_bounds__(256, 1) void lstm_recurrence_kernel(const LstmArgs 
         }
 #pragma unroll
         for (int ks = 0; ks < kLstmKS; ++ks) {
-            const float av = s_a[(wave * kLstmKS + ks) * 64 + lane];
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[ks][ct], acc[ct], 0, 0, 0);
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks][ct], acc[ct], 0, 0, 0);
         }
         // D: col = lane&15, row = 4*(lane>>4) + i
 #pragma unroll

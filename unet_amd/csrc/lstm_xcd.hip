@@ -145,11 +145,27 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
         f32x4 acc[kXSets];
 #pragma unroll
         for (int s = 0; s < kXSets; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The state operands are read a group of 8 k-blocks ahead into a second register set: one read waited for
+        // in front of each 10 MFMAs (80 cycles) put ~19 LDS round trips on the critical path of every time step.
+        constexpr int kGrp = 8;
+        static_assert(kXKg % kGrp == 0, "k-blocks come in whole groups");
+        float bv[2][kGrp];
 #pragma unroll
-        for (int kg = 0; kg < kXKg; ++kg) {
-            const float bv = sh[(4 * kg + ki) * kXCols + r];
+        for (int q = 0; q < kGrp; ++q) bv[0][q] = sh[(4 * q + ki) * kXCols + r];
 #pragma unroll
-            for (int s = 0; s < kXSets; ++s) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[s][kg], bv, acc[s], 0, 0, 0);
+        for (int gi = 0; gi < kXKg / kGrp; ++gi) {
+            const int cur = gi & 1;
+            if (gi + 1 < kXKg / kGrp) {
+#pragma unroll
+                for (int q = 0; q < kGrp; ++q) bv[cur ^ 1][q] = sh[(4 * ((gi + 1) * kGrp + q) + ki) * kXCols + r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < kGrp; ++q)
+#pragma unroll
+                for (int s = 0; s < kXSets; ++s)
+                    acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[s][gi * kGrp + q], bv[cur][q], acc[s], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // sum the 4 k-blocks of a unit (lanes 4*ki apart inside a row of 16), leave the partials in LDS
         float* part = &s_part[t & 1][wave][0][0][0];
