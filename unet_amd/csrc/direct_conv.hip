@@ -172,6 +172,8 @@ hipError_t launch_direct_conv(const UnetmiConvDesc& d, const ConvPlan& pl,
     UNETMI_DIRECT(8, 1, 1) UNETMI_DIRECT(8, 1, 3) UNETMI_DIRECT(8, 1, 7)
     UNETMI_DIRECT(8, 2, 1) UNETMI_DIRECT(8, 2, 3) UNETMI_DIRECT(8, 2, 7)
     UNETMI_DIRECT(2, 16, 1) UNETMI_DIRECT(2, 16, 3) UNETMI_DIRECT(2, 16, 7)
+    UNETMI_DIRECT(4, 16, 1) UNETMI_DIRECT(4, 16, 3) UNETMI_DIRECT(4, 16, 7)
+    UNETMI_DIRECT(2, 32, 1) UNETMI_DIRECT(2, 32, 3) UNETMI_DIRECT(2, 32, 7)
 #undef UNETMI_DIRECT
     return hipErrorInvalidConfiguration;
 }
