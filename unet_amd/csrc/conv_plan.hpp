@@ -109,7 +109,7 @@ inline bool plan_direct(const UnetmiConvDesc& d, ConvPlan* pl) {
     if (d.kw != 1 || d.sw != 1 || d.sh != 1 || d.dh != 1 || d.dw != 1 || d.pw != 0 || d.opw || d.oph) return false;
     if (d.kh != 1 && d.kh != 3 && d.kh != 7) return false;
     const int ctot = (d.in_mode == UNETMI_IN_CONCAT) ? d.C0 + d.C1 : d.C0;
-    if (d.K <= 2) { pl->direct_rpt = 8; pl->direct_kt = d.K; pl->direct_kpad = d.K; }
+    if (d.K <= 2) { pl->direct_rpt = (d.K == 1 && d.kh > 1) ? 16 : 8; pl->direct_kt = d.K; pl->direct_kpad = d.K; }
     else if (d.K <= 32 && ctot * d.kh <= 16 * 7) {
         // a thread owns 4 rows x 16 outputs (each output tile re-reads the input, which is the small side here);
         // with at least as many inputs as outputs it owns 2 rows x all 32 outputs, so the input is read once

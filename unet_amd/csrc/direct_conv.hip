@@ -170,6 +170,7 @@ hipError_t launch_direct_conv(const UnetmiConvDesc& d, const ConvPlan& pl,
         return hipGetLastError();                                                            \
     }
     UNETMI_DIRECT(8, 1, 1) UNETMI_DIRECT(8, 1, 3) UNETMI_DIRECT(8, 1, 7)
+    UNETMI_DIRECT(16, 1, 1) UNETMI_DIRECT(16, 1, 3) UNETMI_DIRECT(16, 1, 7)
     UNETMI_DIRECT(8, 2, 1) UNETMI_DIRECT(8, 2, 3) UNETMI_DIRECT(8, 2, 7)
     UNETMI_DIRECT(2, 16, 1) UNETMI_DIRECT(2, 16, 3) UNETMI_DIRECT(2, 16, 7)
     UNETMI_DIRECT(4, 16, 1) UNETMI_DIRECT(4, 16, 3) UNETMI_DIRECT(4, 16, 7)
