@@ -73,7 +73,11 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
     p.nrows = pl.nrows; p.ncols = pl.ncols; p.plane = pl.plane;
     p.in_tile_floats = pl.in_tile_floats; p.w_tile_floats = pl.w_tile_floats; p.njt = pl.njt;
     p.magic_ncols = magic_u32(pl.ncols); p.magic_nrows = magic_u32(pl.nrows);
-    p.xcd_remap = g_xcd_remap;
+    // One XCD walks a contiguous run of tiles when the layer has a single output phase (plain convolutions and
+    // stride-1 transposed ones): neighbouring tiles' shared halo then meets in that XCD's L2 (headline step
+    // 36.7 -> 36.3 ms).  With two row phases the same order costs time (dec_6: +0.7 ms), so those keep the
+    // round-robin order.
+    p.xcd_remap = g_xcd_remap || (pl.NG == 1 && pl.h.nphase == 1);
     p.bf16 = d.reserved[0] == UNETMI_DTYPE_BF16;
 #ifdef UNETMI_ABLATE
     p.ablate = g_ablate;
