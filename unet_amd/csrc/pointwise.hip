@@ -81,8 +81,13 @@ __global__ __launch_bounds__(256) void layernorm_f_strip_kernel(const void* __re
     __shared__ float s_red[2][4][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = blockIdx.x * 64 + lane;
-    const int nc = blockIdx.y, n = nc / C, c = nc % C;
+    // one XCD walks a contiguous run of (plane, strip) tiles: rows of T floats are not line-aligned, so neighbouring
+    // strips share 128-byte lines, which then meet in one L2 instead of two
+    const unsigned tiles = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned xcd = lin & 7u, q8 = tiles >> 3, r8 = tiles & 7u;
+    const unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    const int t = (int)(tile % gridDim.x) * 64 + lane;
+    const int nc = (int)(tile / gridDim.x), n = nc / C, c = nc % C;
     const int R = (F + 3) >> 2, f0 = w * R;
     const int plane_bytes = F * T * EB;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(
