@@ -66,6 +66,9 @@ WGRAD_CASES = [
     (1, 64, 32, 1, 12, 33, (7, 1), (1, 1), (3, 0), (0, 0)),
     (1, 64, 64, 64, 6, 70, (1, 7), (1, 1), (0, 3), (0, 0)),
     (1, 64, 0, 64, 2, 32, (5, 3), (2, 1), (2, 1), (0, 0)),
+    # thin layers on the streaming kernel: several row chunks and column strips, 3-row kernel, one and two thin channels
+    (1, 8, 3, 2, 70, 130, (3, 1), (1, 1), (1, 0), (0, 0)),
+    (0, 1, 0, 20, 100, 65, (7, 1), (1, 1), (3, 0), (0, 0)),
 ]
 
 

@@ -288,11 +288,125 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
     }
 }
 
+
+// ---- thin layers ------------------------------------------------------------------------------------------------
+// Weight gradient when the SHIFTED operand Q has one or two channels and the kernel is one column wide with unit stride
+// and dilation (the UNet's last decoder 96 -> 1, its first encoder 2 -> 32, the 1 -> 1 head): ~1 GFLOP over hundreds
+// of megabytes, i.e. a streaming reduction, which the matrix kernel above serves at a fifth of the memory rate.
+// A workgroup owns channel a of P, a 64-column strip and a chunk of rows, and walks every sample: a thread (lane =
+// column) loads 8 consecutive rows of P and the 8 + KH - 1 rows of each Q channel they meet (Q is a few megabytes and
+// stays in L2 while every channel of P streams past once), and keeps BB x KH sums.  One partial per workgroup goes to
+// ws[split][tap][a][b]; the fixed-order reduction kernels above finish the sum.
+struct ThinWgradArgs {
+    const float* p0; const float* p1; const float* q; float* ws;
+    int N, A0, A1, PH, PW, QH, ph, chunk_rows;
+};
+
+template <int KH, int BB>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(const ThinWgradArgs g) {
+    constexpr int RPT = 8, NQ = RPT + KH - 1;
+    __shared__ float s_red[4][BB * KH];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // one XCD walks a contiguous run of (channel, row chunk, strip) tiles -- strips fastest -- so the 128-byte lines that
+    // neighbouring strips share (rows are not line-aligned) are fetched by one L2
+    const unsigned tiles = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = lin & 7u, q8 = tiles >> 3, r8 = tiles & 7u;
+    const unsigned t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    const int strip = (int)(t % gridDim.x), chunk = (int)((t / gridDim.x) % gridDim.y), a = (int)(t / (gridDim.x * gridDim.y));
+    const int col = strip * 64 + lane;
+    const bool col_ok = col < g.PW;
+    const bool second = a >= g.A0;
+    const float* pa = second ? g.p1 + (size_t)(a - g.A0) * g.PH * g.PW : g.p0 + (size_t)a * g.PH * g.PW;
+    const size_t p_sample = (size_t)(second ? g.A1 : g.A0) * g.PH * g.PW;
+    const size_t q_plane = (size_t)g.QH * g.PW;
+    const int r_lo = chunk * g.chunk_rows, r_hi = min(r_lo + g.chunk_rows, g.PH);
+
+    float acc[BB][KH];
+#pragma unroll
+    for (int b = 0; b < BB; ++b)
+#pragma unroll
+        for (int r = 0; r < KH; ++r) acc[b][r] = 0.f;
+
+    for (int n = 0; n < g.N; ++n) {
+        const float* pn = pa + (size_t)n * p_sample;
+        const float* qn = g.q + (size_t)n * BB * q_plane;
+        for (int p0 = r_lo + wave * RPT; p0 < r_hi; p0 += 4 * RPT) {
+            float pv[RPT], qv[BB][NQ];
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const bool ok = col_ok && p0 + i < r_hi;
+                pv[i] = ok ? pn[(size_t)(p0 + i) * g.PW + col] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < BB; ++b)
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    const int y = p0 - g.ph + j;
+                    const bool ok = col_ok && (unsigned)y < (unsigned)g.QH;
+                    qv[b][j] = ok ? qn[(size_t)b * q_plane + (size_t)y * g.PW + col] : 0.f;
+                }
+#pragma unroll
+            for (int b = 0; b < BB; ++b)
+#pragma unroll
+                for (int r = 0; r < KH; ++r)
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) acc[b][r] = fmaf(pv[i], qv[b][i + r], acc[b][r]);
+        }
+    }
+    // sum over the 64 columns of a wave, then over the 4 waves, in a fixed order
+#pragma unroll
+    for (int b = 0; b < BB; ++b)
+#pragma unroll
+        for (int r = 0; r < KH; ++r) {
+            float v = acc[b][r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) s_red[wave][b * KH + r] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < BB * KH) {
+        const int b = threadIdx.x / KH, r = threadIdx.x % KH;
+        const float v = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+        const int A = g.A0 + g.A1, split = chunk * gridDim.x + strip, total = KH * A * BB;
+        g.ws[(size_t)split * total + ((size_t)r * A + a) * BB + b] = v;
+    }
+}
+
 struct WgradPlan {
     WgradArgs a;
     int NT, splits, bgroups, ablocks;
     size_t lds_bytes, ws_bytes;
 };
+
+struct ThinWgradPlan { bool ok; int strips, chunks, chunk_rows, splits; size_t ws_bytes; };
+
+// the thin kernel serves: Q of 1 or 2 channels, kernel 1, 3 or 7 rows x 1 column, unit stride and dilation, no column padding
+static ThinWgradPlan plan_wgrad_thin(const WgradArgs& a) {
+    ThinWgradPlan t{};
+    t.ok = a.B <= 2 && a.kw == 1 && a.sw == 1 && a.sh == 1 && a.dw == 1 && a.dh == 1 && a.pw == 0 && a.PW == a.QW &&
+           (a.kh == 1 || a.kh == 3 || a.kh == 7);
+    if (!t.ok) return t;
+    t.strips = (a.PW + 63) / 64;
+    // about a thousand workgroups; a chunk is a whole number of 32-row passes
+    int want = 1024 / std::max(1, t.strips * a.A);
+    want = std::min(std::max(want, 1), 8);
+    t.chunk_rows = std::max(32, ((a.PH + want - 1) / want + 31) / 32 * 32);
+    t.chunks = (a.PH + t.chunk_rows - 1) / t.chunk_rows;
+    t.splits = t.strips * t.chunks;
+    t.ws_bytes = (size_t)t.splits * a.ntaps * a.A * a.B * sizeof(float);
+    return t;
+}
+
+template <int KH, int BB>
+static hipError_t launch_wgrad_thin(const WgradArgs& a, const ThinWgradPlan& t, hipStream_t s) {
+    ThinWgradArgs g;
+    g.p0 = a.p0; g.p1 = a.p1; g.q = a.q; g.ws = a.ws;
+    g.N = a.N; g.A0 = a.A0; g.A1 = a.A1; g.PH = a.PH; g.PW = a.PW; g.QH = a.QH; g.ph = a.ph; g.chunk_rows = t.chunk_rows;
+    hipLaunchKernelGGL((wgrad_thin_kernel<KH, BB>), dim3(t.strips, t.chunks, a.A), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
 
 static int round_pitch(int cols) {          // smallest 4 x odd >= cols
     int p = (cols + 3) / 4;
@@ -341,6 +455,8 @@ static int plan_wgrad(int N, int A0, int A1, int B, int PH, int PW, int QH, int 
     pl->lds_bytes = (size_t)(2 * 64 * kPPitch + a.R * a.BT * a.qpitch + 256) * sizeof(float);
     if (pl->lds_bytes > 160 * 1024) { *why = "ring of input rows exceeds LDS"; return UNETMI_E_UNSUPPORTED; }
     pl->ws_bytes = (size_t)pl->splits * a.ntaps * a.A * a.B * sizeof(float);
+    const ThinWgradPlan thin = plan_wgrad_thin(a);           // thin layers take the streaming kernel and its workspace
+    if (thin.ok) pl->ws_bytes = std::max(pl->ws_bytes, thin.ws_bytes);
     return UNETMI_OK;
 }
 
@@ -401,6 +517,15 @@ int unetmi_conv2d_wgrad(const UnetmiConvDesc* d, const float* in0, const float* 
     else               { pl.a.p0 = dout; pl.a.p1 = dout; pl.a.q = in0; }
     pl.a.ws = static_cast<float*>(ws);
     hipError_t e;
+    const ThinWgradPlan thin = plan_wgrad_thin(pl.a);
+    if (thin.ok) {
+        const int kh = pl.a.kh;
+#define UNETMI_THIN(KH_) (pl.a.B == 1 ? launch_wgrad_thin<KH_, 1>(pl.a, thin, s) : launch_wgrad_thin<KH_, 2>(pl.a, thin, s))
+        e = kh == 1 ? UNETMI_THIN(1) : (kh == 3 ? UNETMI_THIN(3) : UNETMI_THIN(7));
+#undef UNETMI_THIN
+        if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("conv2d_wgrad (thin) launch: ") + hipGetErrorString(e));
+        pl.splits = thin.splits;
+    } else {
     switch (pl.NT) {
         case 1: e = launch_wgrad<1>(pl, s); break;
         case 2: e = launch_wgrad<2>(pl, s); break;
@@ -413,6 +538,7 @@ int unetmi_conv2d_wgrad(const UnetmiConvDesc* d, const float* in0, const float* 
         default: e = launch_wgrad<9>(pl, s); break;
     }
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("conv2d_wgrad launch: ") + hipGetErrorString(e));
+    }
     const int total = pl.a.ntaps * pl.a.A * pl.a.B;
     // one thread per output is a chain of `splits` load latencies: with many splits, 16 lanes share an output
     if (pl.splits >= 32)
