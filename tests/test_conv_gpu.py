@@ -49,6 +49,8 @@ GEOMS = [
     (1, 6, 64, (7, 5), (2, 2), (3, 2), (0, 0), (1, 1), 23, 39),
     (1, 10, 33, (1, 7), (1, 1), (0, 3), (0, 0), (1, 1), 11, 50),
     (1, 12, 1, (7, 1), (1, 1), (3, 0), (0, 0), (1, 1), 30, 40),
+    (0, 1, 96, (7, 1), (1, 1), (3, 0), (0, 0), (1, 1), 21, 70),      # the input gradient of dec_9 as a layer
+    (1, 2, 40, (3, 1), (1, 1), (1, 0), (0, 0), (1, 1), 9, 33),
     # heads / res paths
     (0, 1, 1, (1, 1), (1, 1), (0, 0), (0, 0), (1, 1), 13, 29),
     (0, 16, 32, (1, 1), (1, 1), (0, 0), (0, 0), (1, 1), 13, 29),

@@ -110,7 +110,8 @@ inline bool plan_direct(const UnetmiConvDesc& d, ConvPlan* pl) {
     if (d.kh != 1 && d.kh != 3 && d.kh != 7) return false;
     const int ctot = (d.in_mode == UNETMI_IN_CONCAT) ? d.C0 + d.C1 : d.C0;
     if (d.K <= 2) { pl->direct_rpt = (d.K == 1 && d.kh > 1) ? 16 : 8; pl->direct_kt = d.K; pl->direct_kpad = d.K; }
-    else if (d.K <= 32 && ctot * d.kh <= 16 * 7) {
+    // ... or up to 128 outputs from one or two inputs: a pure write stream (the input gradient of a 96 -> 1 layer)
+    else if ((d.K <= 32 && ctot * d.kh <= 16 * 7) || (d.K <= 128 && ctot <= 2)) {
         // a thread owns 4 rows x 16 outputs (each output tile re-reads the input, which is the small side here);
         // with at least as many inputs as outputs it owns 2 rows x all 32 outputs, so the input is read once
         // (measured at [32, C, 257, 509]: 64 -> 32 1x1 0.73 -> 0.59 ms, 2 -> 32 7x1 0.204 -> 0.180 ms)
