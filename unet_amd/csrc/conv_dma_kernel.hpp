@@ -25,6 +25,8 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 // Staging work a wave does between two taps of its MFMA loop: at most ONE LDS-DMA
 // instruction (its 64-lane piece of input slot q, then of weight slot q - nin_slots).
 // Everything except the lane's (c, r, cl) walk is wave-uniform and stays in SGPRs.
+// NT = threads of the workgroup = elements one slot moves.
+template <int NT>
 struct DmaSide {
     int q, nin_slots, nslots;                  // next slot to issue / input slots / all slots
     const float* in_base; int in_bytes;        // the chunk's input channels (buffer range = zero fill)
@@ -42,22 +44,23 @@ struct DmaSide {
             const int grow = row0 + r, gcol = col0 + c;
             const bool ok = (unsigned)grow < (unsigned)H && (unsigned)gcol < (unsigned)W;
             const int voff = ok ? (cl * HW + grow * W + gcol) * 4 : (int)0x80000000;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(dst_in + qq * 256), 4, voff, 0, 0, 0);
-            c += step_c; r += step_r; cl += step_cl;      // advance this lane by 256 elements
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(dst_in + qq * NT), 4, voff, 0, 0, 0);
+            c += step_c; r += step_r; cl += step_cl;      // advance this lane by NT elements
             if (c >= ncols) { c -= ncols; ++r; }
             if (r >= nrows) { r -= nrows; ++cl; }
         } else if (qq < nslots) {
             const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_base), 0, w_bytes, 0x00020000);
             const int ws = qq - nin_slots;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(dst_w + ws * 1024), 16,
-                                                     ws * 4096 + tid16, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(dst_w + ws * (4 * NT)), 16,
+                                                     ws * (16 * NT) + tid16, 0, 0, 0);
         }
         q = qq + 1;
     }
 };
 
 template <int NG, int TPG, int WM, int WN, int NTW0, int NTW1>
-__global__ __launch_bounds__(256, NG == 1 ? 3 : 2) void conv_dma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (NG == 1 && TPG <= 4) ? 3 : 2) void conv_dma_kernel(const ConvArgs p) {
+    constexpr int NT = 64 * WM * WN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int buf_floats = p.in_tile_floats + p.w_tile_floats;
     float* s_par = smem + 2 * buf_floats;          // [5][NB]: bias, scale, shift, slope, gate
@@ -110,12 +113,12 @@ __global__ __launch_bounds__(256, NG == 1 ? 3 : 2) void conv_dma_kernel(const Co
     const int wlane = half * p.NB + wn * 32 + j;
 
     // ---- DMA bookkeeping -----------------------------------------------------------
-    // Input slot s moves elements e = s*256 + tid of the flat [ci][row][col] image; a
+    // Input slot s moves elements e = s*NT + tid of the flat [ci][row][col] image; a
     // wave's 64 lanes land at consecutive LDS dwords.  (c, r, cl) = this thread's
-    // column / row / channel for the slot about to be issued, stepped by +256 elements.
+    // column / row / channel for the slot about to be issued, stepped by +NT elements.
     const int in_elems = p.ci_chunk * p.plane;
-    const int nin_slots = (in_elems + 255) >> 8;
-    const int nw_slots = ((chunk_w_floats >> 2) + 255) >> 8;
+    const int nin_slots = (in_elems + NT - 1) / NT;
+    const int nw_slots = ((chunk_w_floats >> 2) + NT - 1) / NT;
     int c0, r0, cl0;
     {
         const int rr = __umulhi((unsigned)tid, p.magic_ncols);
@@ -123,11 +126,11 @@ __global__ __launch_bounds__(256, NG == 1 ? 3 : 2) void conv_dma_kernel(const Co
         cl0 = (p.nrows == 1) ? rr : (int)__umulhi((unsigned)rr, p.magic_nrows);
         r0 = rr - cl0 * p.nrows;
     }
-    const int step_rr = 256 / p.ncols, step_c = 256 - step_rr * p.ncols;     // 256 = step_rr*ncols + step_c
+    const int step_rr = NT / p.ncols, step_c = NT - step_rr * p.ncols;       // NT = step_rr*ncols + step_c
     const int step_cl = step_rr / p.nrows, step_r = step_rr - step_cl * p.nrows;
     const float* wsrc_base = p.wpacked + p.w_phase_off[a] + (size_t)cb * p.nchunk * chunk_w_floats;
 
-    DmaSide side;
+    DmaSide<NT> side;
     side.nin_slots = nin_slots; side.nslots = nin_slots + nw_slots; side.q = side.nslots;
     side.row0 = row0; side.col0 = col0; side.H = p.H; side.W = p.W; side.HW = HW;
     side.ncols = p.ncols; side.nrows = p.nrows;
@@ -208,7 +211,8 @@ inline void launch_dma_variant(unsigned grid, size_t lds, hipStream_t stream, co
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<NG, TPG, WM, WN, NTW0, NTW1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     });
-    hipLaunchKernelGGL((conv_dma_kernel<NG, TPG, WM, WN, NTW0, NTW1>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_dma_kernel<NG, TPG, WM, WN, NTW0, NTW1>), dim3(grid), dim3(64 * WM * WN), lds, stream,
+                       p);
 }
 
 }  // namespace unetmi

@@ -8,6 +8,8 @@ parameters themselves stay in the ordinary ``nn.Conv2d`` / ``nn.BatchNorm2d``
 submodules, so ``state_dict`` keys and initialisation are the reference's.
 """
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -15,9 +17,9 @@ from . import _lib
 from .ops import conv2d_fwd, pack_conv_weights, pwconv64
 
 
-# Row tiles per wave requested from the MFMA convolution kernels (reserved[1] of the descriptor): 0 lets the
-# library choose from the grid size; tests set 1 or 4 to run one kernel family on every shape.
-ROW_TILES = 0
+# Kernel family requested from the MFMA convolution kernels (reserved[1] of the descriptor): 0 lets the library
+# choose from the grid size; tests and A/B timing runs set 1, 2, 3 or 4 to run one family on every shape that has it.
+ROW_TILES = int(os.environ.get("UNETMI_ROW_TILES", "0"))
 
 
 def _pair(v):
