@@ -104,9 +104,9 @@ typedef struct UnetmiConvDesc {
     int32_t reserved[3];     /* reserved[0] = UNETMI_DTYPE_* of in0 / in1 / residual / out;
                                 unetmi_conv2d_fwd: reserved[1] = row tiles per wave of the MFMA kernels -- 0: chosen from
                                 the grid size (one for grids of at most 256 workgroups, two where that saves a round
-                                of workgroups, else four; large grids of single-column-phase layers take six when twelve-row
-                                tiles pad the rows no more than eight-row tiles), 4: always four, 1 / 2 / 6: that many
-                                wherever the kernel is built; the result does not depend on it.  reserved[2] = 0.
+                                of workgroups, else four; large grids of single-column-phase layers take five or six when
+                                ten- or twelve-row tiles pad the rows no more than eight-row tiles), 4: always four,
+                                1 / 2 / 5 / 6: that many wherever the kernel is built; the result does not depend on it.  reserved[2] = 0.
                                 unetmi_conv2d_b16_fwd: [1], [2] as described there */
 } UnetmiConvDesc;
 

@@ -101,12 +101,12 @@ def test_conv_bn_act_matches_torch_cpu(device, geom):
 WIDE_GEOMS = [g for g in GEOMS if g[2] > 32]
 
 
-@pytest.mark.parametrize("row_tiles", [1, 2, 4, 6])
+@pytest.mark.parametrize("row_tiles", [1, 2, 4, 5, 6])
 @pytest.mark.parametrize("geom", WIDE_GEOMS, ids=lambda g: "{}c{}-{}k{}x{}s{}x{}_{}x{}".format(
     "t" if g[0] else "", g[1], g[2], g[3][0], g[3][1], g[4][0], g[4][1], g[8], g[9]))
 def test_row_tile_kernel_families(device, geom, row_tiles, monkeypatch):
-    """The library picks one row tile per wave for small grids, two or four otherwise, and six for large
-    single-column-phase grids; all families on the same shapes (every test shape here is a
+    """The library picks one row tile per wave for small grids, two or four otherwise, and five or six for
+    large single-column-phase grids; all families on the same shapes (every test shape here is a
     small grid, so the default run alone would never reach the four-tile kernels), with a concatenated second
     source on the transposed ones."""
     import unet_amd.fused as fused

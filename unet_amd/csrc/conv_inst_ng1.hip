@@ -5,10 +5,14 @@
 namespace unetmi {
 
 bool launch_conv_ng1(int wn, int ntw0, int tpg, unsigned grid, size_t lds, hipStream_t s, const ConvArgs& p) {
-    // six row tiles per wave: twelve output rows per workgroup
+    // five / six row tiles per wave: ten / twelve output rows per workgroup
 #define UNETMI_NG1_T6(NTW_)                                                                 \
     if (wn == 2 && ntw0 == NTW_ && tpg == 6) {                                              \
         launch_dma_variant<1, 6, 2, 2, NTW_, 0>(grid, lds, s, p);                           \
+        return true;                                                                        \
+    }                                                                                       \
+    if (wn == 2 && ntw0 == NTW_ && tpg == 5) {                                              \
+        launch_dma_variant<1, 5, 2, 2, NTW_, 0>(grid, lds, s, p);                           \
         return true;                                                                        \
     }
     UNETMI_NG1_T6(1) UNETMI_NG1_T6(3) UNETMI_NG1_T6(5) UNETMI_NG1_T6(7)

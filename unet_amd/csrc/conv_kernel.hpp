@@ -97,8 +97,8 @@ __device__ __forceinline__ void mfma_rows(f32x16 (&acc)[TPG], float (&a)[2], flo
             }
             if (TPG == 4 && t == 1) { b[nxt][1] = rows[nr][1][nc]; b[nxt][2] = rows[nr][2][nc]; }
             if (TPG == 4 && t == 2) b[nxt][3] = rows[nr][3][nc];
-            if (TPG == 6 && t == 1) { b[nxt][1] = rows[nr][1][nc]; b[nxt][2] = rows[nr][2][nc]; }
-            if (TPG == 6 && t >= 2 && t <= 4) b[nxt][t + 1] = rows[nr][t + 1][nc];
+            if (TPG > 4 && t == 1) { b[nxt][1] = rows[nr][1][nc]; b[nxt][2] = rows[nr][2][nc]; }
+            if (TPG > 4 && t >= 2 && t <= TPG - 2) b[nxt][t + 1] = rows[nr][t + 1][nc];
             __builtin_amdgcn_sched_barrier(0);
         }
         side();      // one piece of staging work per tap, issued in the shadow of the MFMAs above

@@ -98,7 +98,7 @@ struct ConvPlan {
 };
 
 constexpr int kSmallGridWgs = 256;      // a grid of at most this many workgroups takes one row tile per wave
-constexpr int kTallTileWgs = 2048;      // six row tiles per wave from this many workgroups: four rounds of the chip's
+constexpr int kTallTileWgs = 2048;      // five or six row tiles per wave from this many workgroups: four rounds of the chip's
                                         // 512 resident ones, so the last round's idle slots stay small
 
 struct ConvPlan;
@@ -263,24 +263,29 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
             if (r2 * 2 * 108 < r4 * 4 * 95) tpg = 2;
         }
     }
-    // Six row tiles per wave (twelve output rows per workgroup, 96 accumulators, two workgroups per CU instead of
-    // three): every workgroup fetches the whole weight tensor from L2 through its CU's vector L1, whose request
-    // queue is what the large layers wait for, and a taller tile fetches a third less of them -- and of the halo
-    // rows -- per output row.  Taken on large grids when twelve-row tiles do not pad the rows more than eight-row
-    // tiles do (129 rows: 132 against 136).  The channel chunking stays as computed above (same packed image).
-    if (tpg == 4 && built && pl->NG == 1 && (d.reserved[1] == 6 || d.reserved[1] == 0)) {
-        long long wgs6 = 0, rows8 = 0, rows12 = 0;
-        for (int a = 0; a < pl->h.nphase; ++a) {
-            const int t12 = (pl->h.nout[a] + 11) / 12;
-            wgs6 += (long long)t12 * pl->njt * d.N * pl->nco_blk;
-            rows12 += t12 * 12; rows8 += pl->nit[a] * 8;
-        }
+    // Five or six row tiles per wave (ten or twelve output rows per workgroup, 80 / 96 accumulators, two workgroups
+    // per CU instead of three): every workgroup fetches the whole weight tensor from L2 through its CU's vector L1,
+    // whose request queue is what the large layers wait for, and a taller tile fetches fewer of them -- and of the
+    // halo rows -- per output row.  Taken on large grids for the height that pads the rows least, when that is no
+    // more than eight-row tiles pad them (257 rows: 260 in tens, 264 in eights or twelves).  The channel chunking
+    // stays as computed above (same packed image).
+    if (tpg == 4 && built && pl->NG == 1 && (d.reserved[1] == 5 || d.reserved[1] == 6 || d.reserved[1] == 0)) {
+        auto padded = [&](int ti) {
+            long long rows = 0;
+            for (int a = 0; a < pl->h.nphase; ++a) rows += (long long)((pl->h.nout[a] + ti - 1) / ti) * ti;
+            return rows;
+        };
+        int tall = d.reserved[1];
+        if (tall == 0) tall = padded(10) < padded(12) ? 5 : 6;
+        long long wgs_tall = 0;
+        for (int a = 0; a < pl->h.nphase; ++a)
+            wgs_tall += (long long)((pl->h.nout[a] + 2 * tall - 1) / (2 * tall)) * pl->njt * d.N * pl->nco_blk;
         const int nrows_was = pl->nrows;
-        pl->nrows = 11 * pl->h.in_step + std::max(max_nth - 1, 0) * pl->h.tap_step + 1;
+        pl->nrows = (2 * tall - 1) * pl->h.in_step + std::max(max_nth - 1, 0) * pl->h.tap_step + 1;
         pl->plane = pl->nrows * pl->pitch;
         const bool fits = (size_t)(2 * (in_floats(pairs) + w_floats(pairs)) + 5 * pl->NB) * 4 <= 80 * 1024;
-        if (fits && (d.reserved[1] == 6 || (wgs6 >= kTallTileWgs && rows12 <= rows8))) {
-            pl->TPG = 6; pl->TI = 12;
+        if (fits && (d.reserved[1] != 0 || (wgs_tall >= kTallTileWgs && padded(2 * tall) <= padded(8)))) {
+            pl->TPG = tall; pl->TI = 2 * tall;
             pl->in_tile_floats = in_floats(pairs);
             pl->lds_bytes = 0;                                   // no register-staged kernel of this shape
             pl->lds_bytes_dma = (size_t)(2 * (pl->in_tile_floats + pl->w_tile_floats) + 5 * pl->NB) * 4;

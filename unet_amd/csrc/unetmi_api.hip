@@ -137,8 +137,8 @@ int unetmi_conv2d_fwd(const UnetmiConvDesc* d, const float* in0, const float* in
     if (pl.lds_bytes_dma > 80 * 1024) return fail(UNETMI_E_UNSUPPORTED, "LDS images exceed 80 KB");
     if (d->reserved[0] != UNETMI_DTYPE_F32 && d->reserved[0] != UNETMI_DTYPE_BF16)
         return fail(UNETMI_E_BAD_DESC, "unknown activation storage type in reserved[0]");
-    if (d->reserved[1] != 0 && d->reserved[1] != 1 && d->reserved[1] != 2 && d->reserved[1] != 4 && d->reserved[1] != 6)
-        return fail(UNETMI_E_BAD_DESC, "reserved[1] (row tiles per wave) must be 0, 1, 2, 4 or 6");
+    if (d->reserved[1] < 0 || d->reserved[1] > 6 || d->reserved[1] == 3)
+        return fail(UNETMI_E_BAD_DESC, "reserved[1] (row tiles per wave) must be 0, 1, 2, 4, 5 or 6");
     if (!pl.direct && pl.NG == 2 && d->reserved[0] == UNETMI_DTYPE_BF16)
         return fail(UNETMI_E_UNSUPPORTED,
                     "bfloat16 storage on a time-stride-2 transposed conv is not built: widen the operands");
