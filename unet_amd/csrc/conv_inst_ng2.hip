@@ -24,6 +24,14 @@ bool launch_conv_ng2(int wn, int ntw0, int ntw1, int tpg, unsigned grid, size_t 
     }
     UNETMI_NG2_T1(1, 2) UNETMI_NG2_T1(3, 2)
 #undef UNETMI_NG2_T1
+    // five row tiles per wave (ten output rows of each column phase per workgroup, 160 accumulators)
+#define UNETMI_NG2_T5(A_, B_)                                                               \
+    if (wn == 2 && ntw0 == A_ && ntw1 == B_ && tpg == 5) {                                  \
+        launch_dma_variant<2, 5, 2, 2, A_, B_>(grid, lds, s, p);                            \
+        return true;                                                                        \
+    }
+    UNETMI_NG2_T5(1, 2) UNETMI_NG2_T5(3, 2)
+#undef UNETMI_NG2_T5
     return false;
 }
 

@@ -209,6 +209,11 @@ __device__ __forceinline__ void mfma_rows2(f32x16 (&acc0)[TPG], f32x16 (&acc1)[T
                 b[nxt][2] = (ng ? rows1 : rows0)[nrow][2][nc];
             }
             if (TPG == 4 && t == 2) b[nxt][3] = (ng ? rows1 : rows0)[nrow][3][nc];
+            if (TPG > 4 && t == 1) {
+                b[nxt][1] = (ng ? rows1 : rows0)[nrow][1][nc];
+                b[nxt][2] = (ng ? rows1 : rows0)[nrow][2][nc];
+            }
+            if (TPG > 4 && t >= 2 && t <= TPG - 2) b[nxt][t + 1] = (ng ? rows1 : rows0)[nrow][t + 1][nc];
             __builtin_amdgcn_sched_barrier(0);
         }
         side();

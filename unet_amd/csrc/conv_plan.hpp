@@ -269,14 +269,15 @@ inline bool make_plan(const UnetmiConvDesc& d, ConvPlan* pl, std::string* err) {
     // halo rows -- per output row.  Taken on large grids for the height that pads the rows least, when that is no
     // more than eight-row tiles pad them (257 rows: 260 in tens, 264 in eights or twelves).  The channel chunking
     // stays as computed above (same packed image).
-    if (tpg == 4 && built && pl->NG == 1 && (d.reserved[1] == 5 || d.reserved[1] == 6 || d.reserved[1] == 0)) {
+    // With two column phases (twice the accumulators) five row tiles are the most a wave's 256 registers hold.
+    if (tpg == 4 && built && (d.reserved[1] == 5 || (d.reserved[1] == 6 && pl->NG == 1) || d.reserved[1] == 0)) {
         auto padded = [&](int ti) {
             long long rows = 0;
             for (int a = 0; a < pl->h.nphase; ++a) rows += (long long)((pl->h.nout[a] + ti - 1) / ti) * ti;
             return rows;
         };
         int tall = d.reserved[1];
-        if (tall == 0) tall = padded(10) < padded(12) ? 5 : 6;
+        if (tall == 0) tall = (pl->NG == 2 || padded(10) < padded(12)) ? 5 : 6;
         long long wgs_tall = 0;
         for (int a = 0; a < pl->h.nphase; ++a)
             wgs_tall += (long long)((pl->h.nout[a] + 2 * tall - 1) / (2 * tall)) * pl->njt * d.N * pl->nco_blk;
