@@ -368,3 +368,33 @@ def test_blocked_conv_folds_only_eval_batchnorm_and_handles_affine_false():
     untracked = nn.BatchNorm2d(32, track_running_stats=False).eval()
     with pytest.raises(NotImplementedError):
         BlockedConv(conv, untracked, nn.ReLU())._prepare(16, 0, torch.device("cpu"))
+
+
+def test_plan_picks_the_kernel_family_from_the_grid():
+    """Host logic only (unetmi_conv2d_kernel_name launches nothing): which MFMA kernel family a layer gets depends on
+    its grid, the packed weight image does not.  Shapes: the benchmark's 7x5 encoder, its 1x7 layer, its stride-2x2
+    7x5 decoder and the stride-(2,1) decoder whose two row phases (65 and 64 rows) pad worse in ten-row tiles."""
+    from unet_amd import _lib
+    from unet_amd.ops import conv_kernel_name, make_desc
+
+    def name(N, C0, C1, H, W, geom, transposed, rows=0):
+        mode = _lib.IN_CONCAT if C1 else _lib.IN_SINGLE
+        return conv_kernel_name(make_desc(N, C0, C1, H, W, geom, [transposed, mode, _lib.ACT_LEAKY, 0, rows]))
+
+    def image_bytes(N, geom, rows=0):
+        d = make_desc(N, 64, 0, 257, 509, geom, [0, _lib.IN_SINGLE, _lib.ACT_LEAKY, 0, rows])
+        return _lib.lib.unetmi_conv2d_packed_weight_bytes(ctypes.byref(d))
+
+    enc2 = [64, 7, 5, 2, 2, 3, 2, 1, 1, 0, 0]
+    assert name(64, 64, 0, 257, 509, enc2, 0) == "conv_dma_kernel<1, 5, 2, 2, 5, 0>"      # 129 rows: 130 in tens
+    assert name(64, 64, 0, 257, 509, enc2, 0, rows=4) == "conv_dma_kernel<1, 4, 2, 2, 5, 0>"
+    assert name(64, 64, 0, 257, 509, enc2, 0, rows=6) == "conv_dma_kernel<1, 6, 2, 2, 5, 0>"
+    assert name(1, 64, 0, 33, 64, enc2, 0) == "conv_dma_kernel<1, 1, 2, 2, 5, 0>"         # a small grid
+    assert len({image_bytes(N, enc2, r) for N in (1, 8, 64) for r in (0, 1, 2, 4, 5, 6)}) == 1
+    enc1 = [64, 1, 7, 1, 1, 0, 3, 1, 1, 0, 0]
+    assert name(64, 32, 0, 257, 509, enc1, 0) == "conv_dma_kernel<1, 5, 2, 2, 7, 0>"      # 257 rows: 260 in tens
+    dec7 = [64, 7, 5, 2, 2, 3, 2, 1, 1, 0, 0]
+    assert name(64, 64, 64, 129, 255, dec7, 1) == "conv_dma_kernel<2, 5, 2, 2, 3, 2>"     # two column phases: five at most
+    assert name(64, 64, 64, 129, 255, dec7, 1, rows=6) == "conv_dma_kernel<2, 4, 2, 2, 3, 2>"
+    dec6 = [64, 7, 5, 2, 1, 3, 2, 1, 1, 0, 0]
+    assert name(64, 64, 64, 65, 255, dec6, 1) == "conv_dma_kernel<1, 4, 2, 2, 5, 0>"      # 65 + 64 rows: 140 > 136

@@ -39,7 +39,7 @@ def dtype_code(t):
 
 def make_desc(N, C0, C1, H, W, geom, flags, act_pc=0, has_gate=0, has_residual=0, dtype=0):
     K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
-    transposed, in_mode, act, act_first = flags[:4]     # optional fifth entry: row tiles per wave (0 | 1 | 4)
+    transposed, in_mode, act, act_first = flags[:4]     # optional fifth entry: row tiles per wave (0 | 1 | 2 | 4 | 5 | 6)
     d = ConvDesc()
     d.N, d.C0, d.C1, d.H, d.W, d.K = N, C0, C1, H, W, K
     d.OH = conv_out_size(H, kh, sh, ph, dh, oph, transposed)
