@@ -125,6 +125,55 @@ def cpu_baseline(threads):
                        "best of 5 after 2 warm-ups, torch {} CPU".format(torch.__version__))
 
 
+def other_configs(dev, steps=5, warmup=2, batch=32):
+    """The other benchmark workloads on this GPU, a few steps each with inputs resident (N=1, after the headline
+    measurement; they do not enter value / config / roofline): UNet20 at T=509 + ratio-filter application,
+    ResUNet and DSUNet in fp32 and on bfloat16 inputs (batch 32 = one GPU's share) and the training step at
+    batch 8.  ``frac`` prices the whole step against the peak named by ``bound`` (tools/bench_configs.py)."""
+    spec = importlib.util.spec_from_file_location("unetmi_bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+    cfg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cfg)
+    out = []
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    with torch.no_grad():
+        for dtype, names in (("f32", ["unet20", "resunet", "dsunet"]), ("bf16", ["resunet", "dsunet"])):
+            g = torch.Generator().manual_seed(4321)
+            for w in cfg.iter_workloads(names, batch, dev, dtype, g):
+                sec = timed(w["fn"])
+                tflops, roof = cfg.roofline_entry(sec, batch, w["gflop"], w["bf16_operands"], w["hbm_gb"])
+                out.append({"workload": w["workload"], "name": w["name"], "dtype": dtype, "batch": batch,
+                            "ms_per_step": 1e3 * sec, "audio_s_per_s": batch * AUDIO_SECONDS / sec,
+                            "bound": roof["bound"], "frac": roof["frac"], "achieved": roof["achieved"],
+                            "peak": roof["peak"], "unit": roof["unit"]})
+    import unet_amd
+    from unet_amd.train import FlatAdam, train_step
+    net = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=32))
+    unet_amd.seeded_fill_(net, seed=0)
+    net.train().to(dev)
+    opt = FlatAdam(net.parameters(), lr=1e-3)
+    x = synthetic_utterances(0, TRAIN_PER_GPU_BATCH).to(dev)
+    target = torch.cat([torch.rand((1, 1, F_BINS, T_PADDED), generator=torch.Generator().manual_seed(99 + i))
+                        for i in range(TRAIN_PER_GPU_BATCH)]).to(dev)
+    sec = timed(lambda: train_step(net, opt, x, target))
+    tflops = 3 * 64.34e9 * TRAIN_PER_GPU_BATCH / sec / 1e12
+    out.append({"workload": "UNet default config train() step (fwd, MSE, bwd, Adam), batch 8 x [2,257,509]",
+                "name": "train", "dtype": "f32", "batch": TRAIN_PER_GPU_BATCH, "ms_per_step": 1e3 * sec,
+                "audio_s_per_s": TRAIN_PER_GPU_BATCH * AUDIO_SECONDS / sec, "bound": "mfma",
+                "frac": tflops / FP32_MFMA_PEAK_TFLOPS, "achieved": tflops, "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s"})
+    return out
+
+
 TRAIN_PER_GPU_BATCH = 8
 
 
@@ -223,6 +272,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short timings of the other benchmark workloads that an N=1 forward run appends")
     ap.add_argument("--layers", action="store_true", help="per-layer times of the last step on stderr")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward: the headline metric (default); train: the data-parallel training step")
@@ -346,6 +397,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(torch.get_num_threads())
+        if world == 1 and not args.no_other_configs:
+            del net, x, y
+            torch.cuda.empty_cache()
+            result["other_configs"] = other_configs(dev)
         print(json.dumps(result), flush=True)
 
     ranks.shutdown()

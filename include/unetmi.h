@@ -339,7 +339,10 @@ int unetmi_bn_train_stats(int N, int C, int HW, const float* z, float eps, float
  * (about 4096 / C, at most 1024): every layer of the reference's networks fits (C <= 384 at any size); larger
  * requests return UNETMI_E_UNSUPPORTED.  Calls on the same GPU share the array: two calls that overlap in time on
  * one GPU (different streams or threads) race; calls on one stream are ordered and safe.  Calls no hipMalloc,
- * hipFree or any allocating routine. */
+ * hipFree or any allocating routine.  `stream` must belong to the calling thread's current device (checked:
+ * UNETMI_E_BAD_ARG otherwise).  The FIRST call on a device looks the array's address up (hipGetSymbolAddress,
+ * which may load the code object): make that one call outside graph capture; every later call on the device
+ * only launches two kernels. */
 int unetmi_bn_train_stats_static(int N, int C, int HW, const float* z, float eps, float momentum,
                                  float* running_mean, float* running_var, float* mean, float* invstd, void* stream);
 

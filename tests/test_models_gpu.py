@@ -467,6 +467,36 @@ def test_projected_lstm_matches_torch_cpu(device, B, T, kernel, gemm, monkeypatc
     assert_close(got, want, tol=2e-5, what="projected LSTM")
 
 
+def test_projected_lstm_reruns_on_the_barrier_kernel_after_an_abort(device, monkeypatch):
+    """When the XCD-local recurrence reports that a wait gave up, lstm_forward computes the call again on the
+    device-wide-barrier kernel (default ON_ABORT = "rerun") instead of returning NaN; "nan" keeps the NaN.  The
+    abort is simulated by setting the status word the XCD path returns."""
+    import copy
+    import unet_amd
+    import unet_amd.lstm as L
+    from unet_amd.seeding import normal
+    ref = torch.nn.LSTM(384, 640, 3, batch_first=True, proj_size=384)
+    holder = torch.nn.Module()
+    holder.lstm = ref
+    unet_amd.seeded_fill_(holder, seed=72)
+    x = normal("lstm/x_abort", (3, 11, 384), seed=72)
+    with torch.no_grad():
+        want = ref(x)[0]
+    dev = copy.deepcopy(ref).to(device)
+    real = L._forward_channel_major
+
+    def aborting(lstm, xx, cache):
+        out, status = real(lstm, xx, cache)
+        return torch.full_like(out, float("nan")), torch.ones_like(status)
+
+    monkeypatch.setattr(L, "_forward_channel_major", aborting)
+    with pytest.warns(UserWarning, match="device-wide-barrier"):
+        got = L.lstm_forward(dev, x.to(device), {})
+    assert_close(got, want, tol=2e-5, what="projected LSTM after a simulated abort")
+    monkeypatch.setattr(L, "ON_ABORT", "nan")
+    assert torch.isnan(L.lstm_forward(dev, x.to(device), {})).all()
+
+
 # bfloat16 storage (fp32 accumulate) against the fp32 CPU reference: the stated bar is rel-err 1e-2.  It is
 # applied to the relative L2 error; the max-norm figure used for fp32 (max|a-b| / max|b|) is also checked, at
 # 2e-2: ~75 tensors in a row are rounded to 8 mantissa bits and the worst single element of the output lands
@@ -603,6 +633,34 @@ def test_device_stft_and_istft_match_torch(device, L):
     back = tr.istft(got, L)
     assert_close(back, torch.istft(want, n_fft=512, window=win, length=L), tol=1e-5, what="inverse STFT")
     assert_close(back, x, tol=1e-5, what="STFT round trip")
+
+
+def test_helper_two_calls_with_fresh_geometry(device):
+    """One helper instance, two calls whose angle / microphone tensors are temporaries created inside a
+    function (so the allocator hands the second call the first call's addresses): each result must follow ITS
+    geometry.  The beamformer variant is used because both the steering vector and the delay-and-sum channel
+    read the path-length differences."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.DSUNet_helper(oracle.dsunet_architecture(45, 10), DSB=True).eval()
+    unet_amd.seeded_fill_(ref, seed=53)
+    dev = unet_amd.DSUNet_helper(unet_amd.dsunet_architecture(45, 10), DSB=True)
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    wav = normal("helper2/x", (2, 4, 4000), seed=53) * 0.1
+
+    def call(tag):
+        angle = uniform("helper2/angle" + tag, (2,), 0.0, 360.0, seed=53)
+        mic = uniform("helper2/mic" + tag, (2, 4, 3), -0.05, 0.05, seed=53)
+        with torch.no_grad():
+            return ref(wav, angle, mic), dev(wav.to(device), angle.to(device), mic.to(device)).cpu()
+
+    want_a, got_a = call("a")
+    want_b, got_b = call("b")
+    assert (want_a - want_b).abs().max() > 1e-3 * want_a.abs().max()     # the two geometries do differ
+    assert_close(got_a, want_a, what="helper call 1")
+    assert_close(got_b, want_b, what="helper call 2 (fresh angle / mic tensors)")
 
 
 def test_dsunet_helper_wave_to_wave(device):

@@ -11,6 +11,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+_warmed = {}
+
+
 def _both(lib, z, eps=1e-5, momentum=0.1):
     from unet_amd._lib import check
     N, C, HW = z.shape
@@ -23,8 +26,15 @@ def _both(lib, z, eps=1e-5, momentum=0.1):
         mean = torch.full((C,), float("nan"), device=dev)
         invstd = torch.full((C,), float("nan"), device=dev)
         if static:
+            torch.cuda.synchronize()
+            free_before, reserved_before = torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved()
             check(lib.unetmi_bn_train_stats_static(N, C, HW, z.data_ptr(), eps, momentum, rm.data_ptr(), rv.data_ptr(),
                                                    mean.data_ptr(), invstd.data_ptr(), stream), "bn_train_stats_static")
+            torch.cuda.synchronize()
+            if _warmed.get(str(dev)):      # the first call on a device may load the code object; later ones allocate nothing
+                assert torch.cuda.mem_get_info()[0] == free_before, "the static entry point took device memory"
+                assert torch.cuda.memory_reserved() == reserved_before
+            _warmed[str(dev)] = True
         else:
             nbytes = lib.unetmi_bn_workspace_bytes(N, C, HW)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)

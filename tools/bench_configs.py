@@ -57,6 +57,90 @@ def timed(fn, steps, warmup):
     return max(RANKS.gather_float((time.perf_counter() - t0) / steps))
 
 
+def roofline_entry(sec, B, gflop, bf16_operands=False, hbm_gb=None):
+    """Prices the WHOLE forward against the peak that bounds its dominant kernels: the fp32 or (bfloat16 operands)
+    bf16 dense MFMA peak, or -- ResUNet -- HBM bandwidth over the algorithmic bytes of its residual-block layers
+    (one read + one write of the activation per layer)."""
+    tflops = gflop * B / sec / 1e3
+    if hbm_gb is not None:
+        ach = hbm_gb * B / sec
+        return tflops, {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                        "note": "algorithmic bytes of the ResBlock layers over the whole forward's time"}
+    peak = 2500.0 if bf16_operands else 157.3
+    return tflops, {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak}
+
+
+def iter_workloads(names, B, dev, dtype, g):
+    """Yields one dict per workload (name, fn = one step, gflop per utterance, description, dtype, bf16_operands,
+    hbm_gb); the model and its inputs are released when the generator is advanced.  ``names``: None = all."""
+    import unet_amd
+    from unet_amd.ops import crf_apply
+    act = torch.bfloat16 if dtype == "bf16" else torch.float32
+    want = lambda n: names is None or n in names  # noqa: E731
+    if want("unet20"):
+        net = unet_amd.UNet20()
+        net.bf16_matrix = True                       # with bf16: bfloat16 operands (opt-in for this network)
+        unet_amd.seeded_fill_(net, seed=21)
+        net.T = 509
+        net.eval().to(dev)
+        x = torch.rand((B, 14, 257, 509), generator=g).to(dev).to(act)
+        X = torch.view_as_complex(torch.randn((B, 4, 257, 509, 2), generator=g).contiguous()).to(dev)
+        yield dict(name="unet20", fn=lambda: crf_apply(net(x), X), gflop=76.65, dtype=dtype,
+                   bf16_operands=dtype == "bf16", hbm_gb=None,
+                   workload="cRFUNet.UNet20(c_in=14, c_out=4) forward at T=509 + ratio-filter application, one GPU's "
+                            "share of a batch of 256 over 8 GPUs")
+        del net, x, X
+    if want("resunet"):
+        net = unet_amd.ResUNet()
+        unet_amd.seeded_fill_(net, seed=31)
+        net.eval().to(dev)
+        x = torch.randn((B, 4, 257, 501), generator=g).to(dev).to(act)
+        yield dict(name="resunet", fn=lambda: net(x), gflop=46.0, dtype=dtype, bf16_operands=False,
+                   hbm_gb=1.285 if dtype == "f32" else 0.643,
+                   workload="ResUNet() forward, [B,4,257,501]" + (" bfloat16" if dtype == "bf16" else ""))
+        del net, x
+    if want("dsunet"):
+        net = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8))
+        unet_amd.seeded_fill_(net, seed=41)
+        net.eval().to(dev)
+        sf = torch.randn((B, 8, 257, 512), generator=g).to(dev).to(act)
+        SV = torch.randn((B, 4, 514), generator=g).to(dev)
+        ang = torch.rand((B,), generator=g) * 2 * math.pi
+        theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1).to(dev)
+        yield dict(name="dsunet", fn=lambda: net(sf, SV, theta), gflop=129.76, dtype=dtype,
+                   bf16_operands=dtype == "bf16", hbm_gb=None,
+                   workload="DSUNet(UDSS table, model_complexity 45, 8 inputs) forward, sf [B,8,257,512], "
+                            "SV [B,4,514], theta [B,2]")
+        del net, sf, SV, theta
+    if want("helper"):
+        net = unet_amd.DSUNet_helper(unet_amd.dsunet_architecture(45, 8))
+        net.bf16_matrix = dtype == "bf16"
+        unet_amd.seeded_fill_(net, seed=51)
+        net.eval().to(dev)
+        wav = (torch.randn((B, 4, 64000), generator=g) * 0.1).to(dev)
+        angle = (torch.rand((B,), generator=g) * 360).to(dev)
+        mic = ((torch.rand((B, 4, 3), generator=g) - 0.5) * 0.1).to(dev)
+        yield dict(name="helper", fn=lambda: net(wav, angle, mic), gflop=129.76, dtype=dtype,
+                   bf16_operands=dtype == "bf16", hbm_gb=None,
+                   workload="DSUNet_helper wave -> wave: 4-channel 4 s 16 kHz audio, STFT + features + DSUNet + mask "
+                            "+ inverse STFT, [B,4,64000] -> [B,64000]")
+        del net, wav, angle, mic
+    if want("udss"):
+        net = unet_amd.UDSS(type_norm="BatchNorm2d")
+        net.bf16_matrix = True                       # with bf16: bfloat16 operands (opt-in for this network)
+        unet_amd.seeded_fill_(net, seed=61)
+        net.eval().to(dev)
+        sf = torch.randn((B, 4, 257, 512, 2), generator=g).to(dev).to(act)
+        SV = torch.randn((B, 4, 514), generator=g).to(dev)
+        ang = torch.rand((B,), generator=g) * 2 * math.pi
+        theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1).to(dev)
+        yield dict(name="udss", fn=lambda: net(sf, SV, theta), gflop=round(udss_gflop(), 2), dtype=dtype,
+                   bf16_operands=dtype == "bf16", hbm_gb=None,
+                   workload="UDSS(type_norm='BatchNorm2d') complex-valued forward, sf [B,4,257,512,2], SV [B,4,514], "
+                            "theta [B,2]")
+        del net, sf, SV, theta
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
@@ -73,8 +157,6 @@ def main():
     if launcher.needs_self_launch(args.gpus):
         sys.exit(launcher.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     RANKS = launcher.init_ranks(args.gpus)
-    import unet_amd
-    from unet_amd.ops import crf_apply
     from unet_amd.sharding import shard_batch
     dev = RANKS.device
     total = args.global_batch if args.global_batch else args.batch * RANKS.world
@@ -82,96 +164,18 @@ def main():
     B = hi - lo
     g = torch.Generator().manual_seed(4321 + lo)
     seen = RANKS.ranks_seen()
-
-    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-
-    def report(name, sec, gflop, workload, dtype="f32", bf16_operands=False, hbm_gb=None):
-        """One JSON line.  The roofline entry prices the WHOLE forward against the peak that bounds its dominant
-        kernels: the fp32 or (bfloat16 operands) bf16 dense MFMA peak, or -- ResUNet -- HBM bandwidth over the
-        algorithmic bytes of its residual-block layers (one read + one write of the activation per layer)."""
-        if RANKS.rank != 0:
-            return
-        tflops = gflop * B / sec / 1e3                     # per GPU (rank 0's share)
-        if hbm_gb is not None:
-            ach = hbm_gb * B / sec
-            roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                    "note": "algorithmic bytes of the ResBlock layers over the whole forward's time"}
-        else:
-            peak = 2500.0 if bf16_operands else 157.3
-            roof = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak}
-        print(json.dumps({"workload": name, "value": total * AUDIO_SECONDS / sec, "unit": "audio-s/s",
-                          "ms_per_step": 1e3 * sec, "batch": B, "global_batch": total, "n_gpus": RANKS.world,
-                          "ranks_seen": seen, "scaling": "strong" if args.global_batch else "weak", "dtype": dtype,
-                          "gflop_per_utterance": gflop, "tflops": tflops, "roofline": roof,
-                          "config": workload}), flush=True)
-
+    names = None if args.only is None else args.only.split(",")
     with torch.no_grad():
-        if args.only in (None, "unet20"):
-            net = unet_amd.UNet20()
-            net.bf16_matrix = True                       # with --dtype bf16: bfloat16 operands (opt-in for this network)
-            unet_amd.seeded_fill_(net, seed=21)
-            net.T = 509
-            net.eval().to(dev)
-            x = torch.rand((B, 14, 257, 509), generator=g).to(dev).to(act)
-            X = torch.view_as_complex(torch.randn((B, 4, 257, 509, 2), generator=g).contiguous()).to(dev)
-            sec = timed(lambda: crf_apply(net(x), X), args.steps, args.warmup)
-            report("unet20", sec, 76.65, "cRFUNet.UNet20(c_in=14, c_out=4) forward at T=509 + ratio-filter "
-                                         "application, one GPU's share of a batch of 256 over 8 GPUs", args.dtype,
-                   bf16_operands=args.dtype == "bf16")
-            del net, x, X
-        if args.only in (None, "resunet"):
-            net = unet_amd.ResUNet()
-            unet_amd.seeded_fill_(net, seed=31)
-            net.eval().to(dev)
-            x = torch.randn((B, 4, 257, 501), generator=g).to(dev).to(act)
-            sec = timed(lambda: net(x), args.steps, args.warmup)
-            # a bfloat16 input is widened at the boundary by default: the tensors between kernels stay fp32
-            report("resunet", sec, 46.0, "ResUNet() forward, [B,4,257,501]" +
-                   (" bfloat16 in/out, fp32 tensors inside" if args.dtype == "bf16" else ""), args.dtype, hbm_gb=1.285)
-            if args.dtype == "bf16":
-                net.bf16_storage = True
-                sec = timed(lambda: net(x), args.steps, args.warmup)
-                report("resunet_bf16_storage", sec, 46.0, "ResUNet() forward, [B,4,257,501], every intermediate "
-                       "tensor stored as bfloat16 (opt-in)", args.dtype, hbm_gb=0.643)
-            del net, x
-        if args.only in (None, "dsunet"):
-            net = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8))
-            unet_amd.seeded_fill_(net, seed=41)
-            net.eval().to(dev)
-            sf = torch.randn((B, 8, 257, 512), generator=g).to(dev).to(act)
-            SV = torch.randn((B, 4, 514), generator=g).to(dev)
-            ang = torch.rand((B,), generator=g) * 2 * math.pi
-            theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1).to(dev)
-            sec = timed(lambda: net(sf, SV, theta), args.steps, args.warmup)
-            report("dsunet", sec, 129.76, "DSUNet(UDSS table, model_complexity 45, 8 inputs) forward, "
-                                          "sf [B,8,257,512], SV [B,4,514], theta [B,2]", args.dtype,
-                   bf16_operands=args.dtype == "bf16")
-        if args.only in (None, "helper"):
-            net = unet_amd.DSUNet_helper(unet_amd.dsunet_architecture(45, 8))
-            net.bf16_matrix = args.dtype == "bf16"
-            unet_amd.seeded_fill_(net, seed=51)
-            net.eval().to(dev)
-            wav = (torch.randn((B, 4, 64000), generator=g) * 0.1).to(dev)
-            angle = (torch.rand((B,), generator=g) * 360).to(dev)
-            mic = ((torch.rand((B, 4, 3), generator=g) - 0.5) * 0.1).to(dev)
-            sec = timed(lambda: net(wav, angle, mic), args.steps, args.warmup)
-            report("helper", sec, 129.76, "DSUNet_helper wave -> wave: 4-channel 4 s 16 kHz audio, STFT + features + "
-                                          "DSUNet + mask + inverse STFT, [B,4,64000] -> [B,64000]", args.dtype,
-                   bf16_operands=args.dtype == "bf16")
-            del net, wav, angle, mic
-        if args.only in (None, "udss"):
-            net = unet_amd.UDSS(type_norm="BatchNorm2d")
-            net.bf16_matrix = True                       # with --dtype bf16: bfloat16 operands (opt-in for this network)
-            unet_amd.seeded_fill_(net, seed=61)
-            net.eval().to(dev)
-            sf = torch.randn((B, 4, 257, 512, 2), generator=g).to(dev).to(act)
-            SV = torch.randn((B, 4, 514), generator=g).to(dev)
-            ang = torch.rand((B,), generator=g) * 2 * math.pi
-            theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1).to(dev)
-            sec = timed(lambda: net(sf, SV, theta), args.steps, args.warmup)
-            report("udss", sec, round(udss_gflop(), 2), "UDSS(type_norm='BatchNorm2d') complex-valued forward, "
-                                                        "sf [B,4,257,512,2], SV [B,4,514], theta [B,2]", args.dtype,
-                   bf16_operands=args.dtype == "bf16")
+        for w in iter_workloads(names, B, dev, args.dtype, g):
+            sec = timed(w["fn"], args.steps, args.warmup)
+            if RANKS.rank != 0:
+                continue
+            tflops, roof = roofline_entry(sec, B, w["gflop"], w["bf16_operands"], w["hbm_gb"])   # per GPU (rank 0's share)
+            print(json.dumps({"workload": w["name"], "value": total * AUDIO_SECONDS / sec, "unit": "audio-s/s",
+                              "ms_per_step": 1e3 * sec, "batch": B, "global_batch": total, "n_gpus": RANKS.world,
+                              "ranks_seen": seen, "scaling": "strong" if args.global_batch else "weak",
+                              "dtype": w["dtype"], "gflop_per_utterance": w["gflop"], "tflops": tflops,
+                              "roofline": roof, "config": w["workload"]}), flush=True)
     RANKS.shutdown()
 
 

@@ -505,12 +505,13 @@ class DSUNet_helper(nn.Module):
         if self.corr:
             feat_src = torch.cat([X[:, :1], X[:, :1] * X[:, 1:]], dim=1)
         # angle / mic_pos may live on the host (no device wait for the path-length differences then)
-        SV = self.steering_vector(angle, mic_pos, x.device)
+        tdoa = self._tdoa(angle, mic_pos, x.device)     # once per call: the steering vector and the beamformer share it
+        SV = self.steering_vector(angle, mic_pos, x.device, tdoa=tdoa)
         SV = torch.cat((SV.real, SV.imag), -1)
         theta = self.anlge_pre(angle.to(x.device, non_blocking=True))
         parts = [feat_src.real, feat_src.imag]
         if self.DSB:
-            dsb = self.delay_n_sum(feat_src, angle, mic_pos)
+            dsb = self.delay_n_sum(feat_src, angle, mic_pos, tdoa=tdoa)
             parts.append(torch.stack((dsb.real, dsb.imag), dim=1))
         spectral_feature = torch.cat(parts, dim=1).contiguous()
         if self.bf16_matrix:            # opt-in: the network's convolutions with bfloat16 operands (8x faster)
@@ -528,12 +529,9 @@ class DSUNet_helper(nn.Module):
         (DSUNet.py:741-750): they are differences of ~100 m distances, so one fp32 ulp of a distance moves the
         phase at the top bin by 1e-3 rad -- a device reduction that rounds the norm differently would show up at
         that level in the beamformer channel.  Twelve numbers per call: pass ``angle`` / ``mic_pos`` as host tensors
-        and nothing waits for the device; device tensors cost one synchronising copy, paid once per
-        (tensor, version) pair because the result is cached."""
-        key = (angle.data_ptr(), angle._version, mic_pos.data_ptr(), mic_pos._version, str(angle.device), str(device))
-        hit = getattr(self, "_tdoa_cache", None)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        and nothing waits for the device; device tensors cost one synchronising copy per call.  Nothing is kept
+        between calls (the inputs are per-call data: a recycled allocation would alias any address-keyed cache);
+        ``forward`` computes the differences once and hands them to both users."""
         ang = angle.detach().float().cpu()
         mp = mic_pos.detach().float().cpu()
         B = ang.shape[0]
@@ -544,21 +542,20 @@ class DSUNet_helper(nn.Module):
         tdoa = torch.zeros(B, self.n_channel)
         for i in range(self.n_channel):
             tdoa[:, i] = torch.norm(mp[:, i] - loc_src)     # one norm over the whole [B,3] difference, as in the reference
-        out = (tdoa[:, :] - tdoa[:, 0:1]).to(device, non_blocking=True)
-        self._tdoa_cache = (key, out)
-        return out
+        return (tdoa[:, :] - tdoa[:, 0:1]).to(device)
 
-    def _phasors(self, angle, mic_pos, sign, device=None):
+    def _phasors(self, angle, mic_pos, sign, device=None, tdoa=None):
         device = angle.device if device is None else device
-        tdoa = self._tdoa(angle, mic_pos, device)                                             # [B, C]
+        if tdoa is None:
+            tdoa = self._tdoa(angle, mic_pos, device)                                         # [B, C]
         const = sign * 2 * torch.pi * self.sr / (self.n_fft * self.ss)
         j = torch.arange(self.n_hfft, device=device, dtype=torch.float32)
         phase = tdoa[:, :, None] * j[None, None, :] * const                                   # [B, C, F]
         out = torch.polar(torch.ones_like(phase), phase)
         return out / torch.linalg.norm(out, dim=1, keepdim=True)
 
-    def steering_vector(self, angle, mic_pos, device=None):
-        return self._phasors(angle, mic_pos, -1, device)
+    def steering_vector(self, angle, mic_pos, device=None, tdoa=None):
+        return self._phasors(angle, mic_pos, -1, device, tdoa)
 
-    def delay_n_sum(self, X, angle, mic_pos):
-        return torch.einsum("bcft,bcf->bft", X, self._phasors(angle, mic_pos, +1, X.device))
+    def delay_n_sum(self, X, angle, mic_pos, tdoa=None):
+        return torch.einsum("bcft,bcf->bft", X, self._phasors(angle, mic_pos, +1, X.device, tdoa))

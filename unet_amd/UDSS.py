@@ -754,12 +754,13 @@ class UDSS_helper(_helper_base()):
         feat_src = X
         if self.corr:
             feat_src = torch.cat([X[:, :1], X[:, :1] * X[:, 1:]], dim=1)
-        SV = self.steering_vector(angle, mic_pos, x.device)
+        tdoa = self._tdoa(angle, mic_pos, x.device)
+        SV = self.steering_vector(angle, mic_pos, x.device, tdoa=tdoa)
         SV = torch.cat((SV.real, SV.imag), -1)
         theta = self.anlge_pre(angle.to(x.device, non_blocking=True))
         feat = feat_src
         if self.DSB:
-            feat = torch.cat((feat_src, self.delay_n_sum(feat_src, angle, mic_pos)[:, None]), dim=1)
+            feat = torch.cat((feat_src, self.delay_n_sum(feat_src, angle, mic_pos, tdoa=tdoa)[:, None]), dim=1)
         spectral_feature = torch.view_as_real(feat.contiguous())            # [B, C(+1), F, T, 2]
         if self.bf16_matrix:
             self.net.bf16_matrix = True

@@ -8,8 +8,15 @@ the header declares.  There is no CPU or eager fallback.
 import ctypes
 import os
 
+import sys
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunetmi.so")
+# Developer probes (tools/abl/run.sh) time instrumented builds of the library; they point at one here instead of
+# overwriting the product file.  Never silent: the override is announced on stderr.
+if os.environ.get("UNETMI_LIBRARY"):
+    LIB_PATH = os.path.abspath(os.environ["UNETMI_LIBRARY"])
+    sys.stderr.write("unet_amd: loading {} (UNETMI_LIBRARY override)\n".format(LIB_PATH))
 
 # activation / input-mode codes of include/unetmi.h
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SILU, ACT_SOFTPLUS, ACT_SIGMOID, ACT_TANH, ACT_GELU = range(8)

@@ -283,11 +283,22 @@ constexpr int kMaxDevices = 64;
 static std::mutex g_scratch_mutex;
 static double* g_scratch_ptr[kMaxDevices];                         // guarded by g_scratch_mutex
 
-static int static_scratch_of_current_device(double** out) {
+// The array's copy on the device that owns `stream`, which must be the calling thread's current device (the lookup
+// resolves the symbol on the current device; handing a kernel on one GPU another GPU's address would fault).
+static int static_scratch_of_stream_device(hipStream_t stream, double** out) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("static scratch: hipGetDevice: ") + hipGetErrorString(e));
     if (dev < 0 || dev >= kMaxDevices) return api_fail(UNETMI_E_UNSUPPORTED, "static scratch: device index out of range");
+    if (stream) {                                  // the null stream belongs to the current device by definition
+        hipDevice_t sdev = -1;
+        e = hipStreamGetDevice(stream, &sdev);
+        if (e != hipSuccess)
+            return api_fail(UNETMI_E_HIP, std::string("static scratch: hipStreamGetDevice: ") + hipGetErrorString(e));
+        if ((int)sdev != dev)
+            return api_fail(UNETMI_E_BAD_ARG, "static scratch: the stream belongs to device " + std::to_string((int)sdev) +
+                                                  " but device " + std::to_string(dev) + " is current");
+    }
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
         void* p = nullptr;
@@ -373,9 +384,9 @@ int unetmi_bn_train_stats_static(int N, int C, int HW, const float* z, float eps
                             " bytes of partial sums exceed the " + std::to_string(kStaticScratchDoubles * sizeof(double)) +
                             "-byte static scratch; use unetmi_bn_train_stats with a workspace");
     double* ws = nullptr;
-    if (int rc = static_scratch_of_current_device(&ws)) return rc;
-    a.ws = ws;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = static_scratch_of_stream_device(s, &ws)) return rc;
+    a.ws = ws;
     // every partial the finish kernel reads is written by the reduce kernel of this call: nothing to clear
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(a.S, C), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(C), dim3(64), 0, s, a.ws, a.S, (long long)N * HW, eps, momentum,

@@ -18,8 +18,11 @@ from .ops import conv2d_fwd, pack_conv_weights, pwconv64
 
 
 # Kernel family requested from the MFMA convolution kernels (reserved[1] of the descriptor): 0 lets the library
-# choose from the grid size; tests and A/B timing runs set 1, 2, 3 or 4 to run one family on every shape that has it.
+# choose from the grid size; tests and A/B timing runs set 1, 2, 4, 5 or 6 (row tiles per wave; there is no 3) to
+# run one family on every shape that has it.
 ROW_TILES = int(os.environ.get("UNETMI_ROW_TILES", "0"))
+if ROW_TILES not in (0, 1, 2, 4, 5, 6):
+    raise ImportError("unet_amd: UNETMI_ROW_TILES={} is not a kernel family (0, 1, 2, 4, 5 or 6)".format(ROW_TILES))
 
 
 def _pair(v):

@@ -21,6 +21,12 @@ XCD_BATCH_PER_LAUNCH = 32          # XCD-local kernel (unetmi_lstm_recurrence_xc
 # device-wide barrier per step).
 KERNEL = "xcd"
 
+# What lstm_forward does when the XCD kernel reports that a wait gave up (its 32 workgroups per XCD must all be
+# resident at once; a GPU shared with other work can starve one): "rerun" (default) reads the status word on the
+# host -- one synchronisation per call -- and computes the call again with the device-wide-barrier kernel, whose
+# host side checks residency before launching; "nan" keeps everything asynchronous and turns the output into NaN.
+ON_ABORT = "rerun"
+
 
 def supported(lstm):
     return (isinstance(lstm, nn.LSTM) and lstm.hidden_size in (640, 300) and lstm.proj_size > 0 and lstm.batch_first
@@ -101,23 +107,32 @@ def _forward_channel_major(lstm, x, cache):
         aborted = aborted | _recurrence(wrec, gx[0], hfull[0], True, channel_major=True)
         seq = _pointwise(w_hr, None, cache, ("hr", layer))(hfull)                  # [1, proj, T+1, BP]
     out = seq[0, :, 1:, :B].permute(2, 1, 0).contiguous()
-    return torch.where(aborted != 0, torch.full_like(out, float("nan")), out)
+    return out, aborted
 
 
-def lstm_forward(lstm, x, cache):
+def lstm_forward(lstm, x, cache, _force_grid=False):
     """x [B, T, input] -> [B, T, proj]; zero initial state, inference only."""
     if not supported(lstm):
         raise NotImplementedError("lstm_forward: built for batch_first projected LSTMs with hidden size 640 or 300")
     if not x.is_cuda or x.dtype != torch.float32:
         raise ValueError("lstm_forward: x must be an fp32 device tensor")
     B, T, _ = x.shape
-    use_xcd = _xcd_kernel_fits(x.device, lstm.hidden_size)
+    use_xcd = _xcd_kernel_fits(x.device, lstm.hidden_size) and not _force_grid
     group = XCD_BATCH_PER_LAUNCH if use_xcd else MAX_BATCH_PER_LAUNCH
     if B > group:                                   # sequences are independent: run them in groups
-        return torch.cat([lstm_forward(lstm, x[i:i + group], cache) for i in range(0, B, group)], dim=0)
+        return torch.cat([lstm_forward(lstm, x[i:i + group], cache, _force_grid) for i in range(0, B, group)], dim=0)
     if use_xcd and GEMM == "conv":
         with torch.no_grad(), torch.cuda.device(x.device):
-            return _forward_channel_major(lstm, x, cache)
+            out, aborted = _forward_channel_major(lstm, x, cache)
+            if ON_ABORT == "rerun":
+                if int(aborted.item()) == 0:
+                    return out
+                import warnings
+                warnings.warn("unet_amd.lstm: the XCD-local recurrence kernel gave up waiting for a workgroup that was "
+                              "not resident (GPU shared with other work?); running the call again on the "
+                              "device-wide-barrier kernel")
+                return lstm_forward(lstm, x, cache, _force_grid=True)
+            return torch.where(aborted != 0, torch.full_like(out, float("nan")), out)
     H = lstm.hidden_size
     BP = (B + 15) // 16 * 16
     dev = x.device

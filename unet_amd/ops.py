@@ -551,6 +551,8 @@ def _gather_f32_cuda(src, map):
     return out
 
 
+# flag / status words of the persistent recurrence kernels, one buffer per (device, stream, kind, H): a launch
+# clears its flags with a memset on ITS stream, so two streams must not share the words of a kernel still spinning
 _lstm_scratch = {}
 
 
@@ -573,9 +575,9 @@ def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major):
     if not ok or G != 4 * H or tuple(wrec.shape) != (G, H):
         raise ValueError("unetmi::lstm_recurrence: wrec [4H,H] with gx [T,4H,BP], hfull [T+1,H,BP], or (XCD kernel) "
                          "gx [4H,T+1,BP], hfull [H,T+1,BP] expected")
-    key = (gx.device, bool(xcd), H)
     with torch.cuda.device(gx.device):
         stream = _stream(gx)
+        key = (gx.device, stream, bool(xcd), H)
         if xcd:
             nbytes = _lib.lib.unetmi_lstm_recurrence_xcd_workspace_bytes()
             ws = _lstm_scratch.get(key)
@@ -625,11 +627,11 @@ def _gru_recurrence_cuda(whh, bhh, gx, hfull, channel_major):
     H = G // 3
     if G != 3 * H or tuple(whh.shape) != (G, H) or bhh.numel() != G or tuple(hfull.shape) != (T + 1, H, BP):
         raise ValueError("unetmi::gru_recurrence: whh [3H,H], bhh [3H], gx [T,3H,BP] or [3H,T,BP], hfull [T+1,H,BP] expected")
-    key = (gx.device, "gru", H)
-    sync = _lstm_scratch.get(key)
-    if sync is None:
-        sync = _lstm_scratch[key] = torch.empty(H // 4 + 1, dtype=torch.int32, device=gx.device)
     with torch.cuda.device(gx.device):
+        key = (gx.device, _stream(gx), "gru", H)
+        sync = _lstm_scratch.get(key)
+        if sync is None:
+            sync = _lstm_scratch[key] = torch.empty(H // 4 + 1, dtype=torch.int32, device=gx.device)
         check(_lib.lib.unetmi_gru_recurrence(T, BP, H, _ptr(whh), _ptr(bhh), _ptr(gx), int(channel_major), _ptr(hfull),
                                              _ptr(sync), _stream(gx)), "unetmi_gru_recurrence")
     return sync[-1].clone()
