@@ -400,7 +400,9 @@ def main():
         if world == 1 and not args.no_other_configs:
             del net, x, y
             torch.cuda.empty_cache()
-            result["other_configs"] = other_configs(dev)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):      # the reference's DSUNet constructor prints; stdout carries ONE line
+                result["other_configs"] = other_configs(dev)
         print(json.dumps(result), flush=True)
 
     ranks.shutdown()

@@ -292,6 +292,18 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
 int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
                           const float* bias, const float* scale, const float* shift, const float* act_param,
                           const float* gate, void* out, void* stream);
+/* The last decoder of such a chain together with the network's 1x1 mask head and its squash
+ * (DSUNet.py:616-628 with CRM.forward :355-359: decoder -> Conv2d(C, 2, 1) -> tanh / sigmoid / softplus): the
+ * decoder's result stays in the fp32 accumulators (it is never rounded or written), and per pixel
+ *   out[p] = head_act(sum_k head_w[p][k] * decoder_out[k] + head_b[p]),   p < head_channels <= 4.
+ * head_w [head_channels][K] fp32, head_b [head_channels] or null, head_act = UNETMI_ACT_* (not LeakyReLU).
+ * out: fp32 [N][head_channels][OH][OW], or with interleaved != 0 [N][OH][OW][head_channels] (two channels that
+ * way are a complex64 [N][OH][OW] tensor, which is what the reference's CRM head returns).  The descriptor's
+ * reserved[2] is ignored. */
+int unetmi_conv2d_b16_head_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
+                               const float* bias, const float* scale, const float* shift, const float* act_param,
+                               const float* gate, const float* head_w, const float* head_b, int head_channels,
+                               int head_act, int interleaved, float* out, void* stream);
 /* Layout conversion either side of such a chain: src NCHW [N,C,HW] (UNETMI_DTYPE_*) -> blocked, and back.
  * These have no counterpart in the reference (its tensors are NCHW throughout). */
 int unetmi_blocked_from_nchw(int N, int C, int HW, const void* src, int src_dtype, void* dst, void* stream);

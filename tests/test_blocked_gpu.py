@@ -124,6 +124,24 @@ def test_conv_b16_matches_cpu(device, case, halves):
     raw = got.data.permute(0, 1, 4, 2, 3).reshape(N, -1, *got.data.shape[2:4])
     if raw.shape[1] > K:
         assert raw[:, K:].float().abs().max().item() == 0.0
+    # the layer + a 1x1 head + squash as one launch (the layer's result never leaves the fp32 accumulators):
+    # planar and pixel-interleaved output, 1..4 head channels
+    from unet_amd import _lib
+    P = 1 + (hash(case) % 4)
+    head_conv = nn.Conv2d(K, P, 1, bias=(hash(case) % 3) != 0)
+    with torch.no_grad():
+        head_conv.weight.copy_(torch.randn(head_conv.weight.shape, generator=g) / K ** 0.5)
+        if head_conv.bias is not None:
+            head_conv.bias.copy_(torch.randn(P, generator=g) * 0.1)
+        want_head = torch.tanh(head_conv(want))
+    for interleaved in (False, True):
+        m = layer.with_head(b0, b1, head_conv.to(device), _lib.ACT_TANH, interleaved=interleaved, gate=gate.to(device)).cpu()
+        head_conv.cpu()
+        if interleaved:
+            assert tuple(m.shape) == (N,) + tuple(want.shape[2:]) + (P,)
+            m = m.permute(0, 3, 1, 2)
+        e = rel_err(m, want_head)
+        assert e <= 1e-4, "layer + head ({} channels, interleaved={}): rel-err {:.3e}".format(P, interleaved, e)
 
 
 def test_conv_b16_empty_batch(device):

@@ -161,3 +161,70 @@ def test_projected_lstm_full_length(device, kernel, monkeypatch):
     # a second run gives the same bits: no read of a state row that is still in flight
     again = lstm_forward(dev, x.to(device), {}).cpu()
     assert torch.equal(got, again)
+
+
+def bf16_figures(got, want):
+    """(relative L2 error, max-norm error) of a bfloat16-path result against the fp32 CPU forward."""
+    got, want = got.detach().cpu(), want.detach().cpu()
+    if got.is_complex():
+        got, want = torch.view_as_real(got), torch.view_as_real(want)
+    got, want = got.float(), want.float()
+    return ((got - want).norm() / want.norm()).item(), ((got - want).abs().max() / want.abs().max()).item()
+
+
+BF16_TOL = 1e-2          # the stated bfloat16 bar, held on BOTH figures for the paths a bfloat16 input takes by default
+
+
+def test_resunet_bf16_full_length(device):
+    """ResUNet on a bfloat16 input at the benchmark length (T=501, batch 2) against the fp32 oracle on the same
+    (bf16-representable) values (ResUNet.py:161-220): the default path, and the opt-in all-bfloat16 storage whose
+    figures are printed and held to the looser bar documented for it."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal
+    ref = oracle.ResUNet().eval()
+    unet_amd.seeded_fill_(ref, seed=36)
+    dev = unet_amd.ResUNet()
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    x = torch.cat([normal("resunet/x501", (1, 4, 257, 501), seed=36),
+                   normal("resunet/x501b", (1, 4, 257, 501), seed=37)]).to(torch.bfloat16)
+    with torch.no_grad():
+        want = ref(x.float())
+        got = dev(x.to(device))
+        assert got.dtype == torch.bfloat16 and tuple(got.shape) == (2, 2, 257, 501)
+        l2, mx = bf16_figures(got, want)
+        print("ResUNet bf16 T=501 (default path): relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+        assert l2 <= BF16_TOL and mx <= BF16_TOL
+        dev.bf16_storage = True
+        got = dev(x.to(device))
+        l2, mx = bf16_figures(got, want)
+        print("ResUNet bf16 T=501 (opt-in bf16_storage): relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+        assert l2 <= BF16_TOL and mx <= 2e-2
+
+
+def test_dsunet_bf16_full_length(device):
+    """DSUNet on a bfloat16 input at T=512 (batch 2), bfloat16 operands on the blocked layout (the default for a
+    bfloat16 input), against the fp32 oracle (DSUNet.py:582-628): both figures within 1e-2."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.DSUNet(oracle.dsunet_architecture(45, 8)).eval()
+    unet_amd.seeded_fill_(ref, seed=44)
+    dev = unet_amd.DSUNet(unet_amd.dsunet_architecture(45, 8))
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    sf = torch.cat([normal("dsunet/sf512", (1, 8, 257, 512), seed=44),
+                    normal("dsunet/sf512b", (1, 8, 257, 512), seed=45)]).to(torch.bfloat16)
+    SV = torch.cat([normal("dsunet/SV512", (1, 4, 514), seed=44), normal("dsunet/SV512b", (1, 4, 514), seed=45)])
+    ang = torch.cat([uniform("dsunet/theta512", (1,), 0.0, 2 * np.pi, seed=44),
+                     uniform("dsunet/theta512b", (1,), 0.0, 2 * np.pi, seed=45)])
+    theta = torch.stack([torch.sin(ang), torch.cos(ang)], dim=1)
+    with torch.no_grad():
+        want = ref(sf.float(), SV, theta)
+        got = dev(sf.to(device), SV.to(device), theta.to(device))
+    assert got.dtype == torch.complex64 and tuple(got.shape) == (2, 257, 512)
+    assert dev._blocked, "the blocked bf16 path was not taken"
+    l2, mx = bf16_figures(got, want)
+    print("DSUNet bf16 T=512 (bf16 operands, blocked layout): relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+    assert l2 <= BF16_TOL and mx <= BF16_TOL

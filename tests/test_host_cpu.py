@@ -335,6 +335,10 @@ def test_every_entry_point_is_a_dispatcher_op_with_shape_inference():
         assert ops.conv2d_b16_fwd(b, 8, None, 0, w, c, c, c, None, None, geom, [0, 0, 0, 1, 0]).shape == (2, 2, 5, 7, 8)
         out = ops.conv2d_b16_fwd(b, 8, None, 0, w, c, c, c, None, None, geom, [0, 0, 0, 1, 1])
         assert out.shape == (2, 4, 5, 7) and out.dtype == torch.float32
+        hw = torch.empty(2, 4)
+        out = ops.conv2d_b16_head_fwd(b, 8, None, 0, w, c, c, c, None, None, hw, None, geom, [0, 0, 0, 1, 6, 1])
+        assert out.shape == (2, 5, 7, 2) and out.dtype == torch.float32           # interleaved: a complex64 [2,5,7]
+        assert ops.conv2d_b16_head_fwd(b, 8, None, 0, w, c, c, c, None, None, hw, None, geom, [0, 0, 0, 1, 6, 0]).shape == (2, 2, 5, 7)
         assert ops.adam_step(c, c, c, c, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 1) is None
         assert ops.instnorm_act(z, None, None, 1e-5, 1, torch.empty(1), None).shape == z.shape
         m2, i2 = ops.bn_batch_stats(z, 1e-5)

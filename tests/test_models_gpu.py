@@ -497,15 +497,17 @@ def test_projected_lstm_reruns_on_the_barrier_kernel_after_an_abort(device, monk
     assert torch.isnan(L.lstm_forward(dev, x.to(device), {})).all()
 
 
-# bfloat16 storage (fp32 accumulate) against the fp32 CPU reference: the stated bar is rel-err 1e-2.  It is
-# applied to the relative L2 error; the max-norm figure used for fp32 (max|a-b| / max|b|) is also checked, at
-# 2e-2: ~75 tensors in a row are rounded to 8 mantissa bits and the worst single element of the output lands
-# between 0.7e-2 and 1.1e-2 depending on the input.
+# bfloat16 against the fp32 CPU reference: the stated bar is rel-err 1e-2.  The paths a bfloat16 input takes BY
+# DEFAULT (ResUNet: bfloat16 at the boundary; DSUNet: bfloat16 operands on the blocked layout) are held to it on both
+# the relative L2 error and the max-norm figure used for fp32 (max|a-b| / max|b|); the opt-in all-bfloat16 storage
+# paths are held to 1e-2 on L2 and 2e-2 on max-norm (~75 tensors in a row rounded to 8 mantissa bits: the worst
+# single element of the output lands between 0.7e-2 and 1.4e-2 depending on the input).
 BF16_L2_TOL = 1e-2
 BF16_MAX_TOL = 2e-2
+BF16_DEFAULT_PATH_TOL = 1e-2
 
 
-def assert_bf16_close(got, want, what):
+def assert_bf16_close(got, want, what, max_tol=None):
     got, want = got.detach().cpu(), want.detach().cpu()
     if got.is_complex():
         got, want = torch.view_as_real(got), torch.view_as_real(want)
@@ -514,7 +516,7 @@ def assert_bf16_close(got, want, what):
     mx = ((got - want).abs().max() / want.abs().max()).item()
     print("{}: relative L2 {:.3e}, max-norm {:.3e}".format(what, l2, mx))          # both figures, every bf16 test
     assert l2 <= BF16_L2_TOL, "{}: relative L2 error {:.3e} > {:.1e}".format(what, l2, BF16_L2_TOL)
-    assert_close(got, want, tol=BF16_MAX_TOL, what=what)
+    assert_close(got, want, tol=BF16_MAX_TOL if max_tol is None else max_tol, what=what)
 
 
 def test_resunet_bf16_storage(device):
@@ -534,8 +536,7 @@ def test_resunet_bf16_storage(device):
         want = ref(xb.float())                      # same (bf16-representable) input values
         got = dev(xb.to(device))                    # default: bfloat16 at the boundary, fp32 tensors inside
         assert got.dtype == torch.bfloat16
-        assert_bf16_close(got, want, "ResUNet bf16 in/out, fp32 inside")
-        assert_close(got.float(), want, tol=1e-2, what="ResUNet bf16 in/out: the fp32 tests' max-norm figure at 1e-2")
+        assert_bf16_close(got, want, "ResUNet bf16 in/out, fp32 inside", max_tol=BF16_DEFAULT_PATH_TOL)
         dev.bf16_storage = True                     # every intermediate tensor bfloat16
         got = dev(xb.to(device))
     assert got.dtype == torch.bfloat16
@@ -565,7 +566,7 @@ def test_dsunet_bf16(device):
             got = dev(sf.to(device), SV.to(device), theta.to(device))
             assert got.dtype == torch.complex64
             what = "DSUNet bf16 " + ("operands, blocked layout" if matrix else "storage, NCHW")
-            assert_bf16_close(got, want, what)
+            assert_bf16_close(got, want, what, max_tol=BF16_DEFAULT_PATH_TOL if matrix else None)
     assert dev._blocked, "the blocked bf16 path was not taken"
 
 

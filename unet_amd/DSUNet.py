@@ -387,7 +387,8 @@ class DSUNet(nn.Module):
         # (unet_amd/blocked.py) when every layer is one that kernel serves; False keeps the NCHW
         # bfloat16-storage kernels (fp32 products)
         self.bf16_matrix = True
-        self.bf16_full_res_halves = 2
+        self.bf16_two_half_encoders = (0,)
+        self.bf16_two_half_decoders = (L - 1,)
 
     def _blocked_layers(self):
         """BlockedConv per encoder / decoder / head, or False when a layer is outside that kernel."""
@@ -402,18 +403,23 @@ class DSUNet(nn.Module):
                     conv.out_channels <= 128 and \
                     getattr(conv, "padding_mode", "zeros") == "zeros"
             built = False
-            if ok:
-                # The first encoder and the head are bound by their activation traffic, not by the matrix cores:
-                # there a weight goes in as bfloat16 plus its rounding remainder (two MFMAs per product, fp32-weight
-                # accuracy).  Measured at batch 32: 6.41 -> 6.52 ms, max-norm error 9.9e-3 -> 8.4e-3; the last
-                # decoder as well would give 7.8e-3 for 7.17 ms.
-                hv = self.bf16_full_res_halves
-                built = dict(enc=[BlockedConv(m.conv, m.bn, m.relu, halves=hv if i < 1 else 1)
+            squash = activation_code(self.mask.squash)
+            if ok and squash is not None and squash[0] != _lib.ACT_LEAKY:
+                # Which layers take a weight as bfloat16 PLUS its rounding remainder (two MFMAs per product,
+                # fp32-weight accuracy at twice the matrix work): by default the first encoder (bound by its
+                # activation traffic, so the second MFMA is nearly free) and the last decoder (its error reaches the
+                # mask without being averaged by later layers).  The head is not a layer of its own: the last decoder
+                # keeps its result in the fp32 accumulators and applies the 1x1 head and the squash there
+                # (BlockedConv.with_head), so neither that tensor nor the head's weights are ever rounded.
+                # Measured at T=512, batch 32 (tools/dsunet_halves_probe.py full; max-norm error / ms): no layer 1.18e-2 /
+                # 6.07, these two 7.8e-3 / 6.82, the first two encoders and last two decoders 7.0e-3 / 7.50,
+                # every layer 6.7e-3 / 10.2.
+                e2, d2 = self.bf16_two_half_encoders, self.bf16_two_half_decoders
+                built = dict(enc=[BlockedConv(m.conv, m.bn, m.relu, halves=2 if i in e2 else 1)
                                   for i, m in enumerate(self.encoders)],
-                             dec=[BlockedConv(m.transconv, m.bn, m.relu) for m in self.decoders],
-                             # the head writes its two channels as fp32 NCHW; the squash runs on that small
-                             # tensor (inlined per accumulator, the transcendental epilogue doubles the launch)
-                             head=BlockedConv(self.linear, None, None, halves=hv, nchw_out=True))
+                             dec=[BlockedConv(m.transconv, m.bn, m.relu, halves=2 if i in d2 else 1)
+                                  for i, m in enumerate(self.decoders)],
+                             head_act=squash[0])
             object.__setattr__(self, "_blocked", built)
         return self._blocked
 
@@ -425,12 +431,11 @@ class DSUNet(nn.Module):
         for i, enc in enumerate(layers["enc"]):
             skips.append(x)
             x = enc(x, None, self.attractEncoders[i](attract).float().contiguous())
-        for i, dec in enumerate(layers["dec"]):
+        for i, dec in enumerate(layers["dec"][:-1]):
             x = dec(x, None if i == 0 else skips[L - i])
-        m = layers["head"](x)                                          # fp32 [B, 2, F, T]
-        if self.mask.squash is not None:
-            m = self.mask.squash(m)
-        return torch.complex(m[:, 0, ...], m[:, 1, ...])
+        # last decoder + Conv2d(C, 2, 1) + squash in one launch, written as interleaved (re, im) pairs
+        m = layers["dec"][-1].with_head(x, skips[1] if L > 1 else None, self.linear, layers["head_act"], interleaved=True)
+        return torch.view_as_complex(m)                                # complex64 [B, F, T]
 
     def forward(self, sf, SV, theta):
         require_device_tensor(sf, "DSUNet")

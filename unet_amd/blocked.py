@@ -142,3 +142,19 @@ class BlockedConv:
         st = self._prepare(x.C, 0 if skip is None else skip.C, x.data.device)
         return conv2d_b16(x, skip, st["w"], st["bias"], st["scale"], st["shift"], st["ap"], gate, self.geom,
                           self.transposed, self.act_code, 0, self.halves, self.nchw_out)
+
+    def with_head(self, x, skip, head_conv, head_act_code, interleaved=True, gate=None):
+        """This layer followed by the 1x1 convolution ``head_conv`` (at most four output channels) and its
+        activation as ONE launch: the layer's output stays in the fp32 accumulators and only the head's result is
+        written -- fp32 [N, OH, OW, P] (``interleaved``; two channels are a complex64 tensor) or [N, P, OH, OW]."""
+        st = self._prepare(x.C, 0 if skip is None else skip.C, x.data.device)
+        # the head's parameters are used as they are (views when they already are fp32 tensors on the device)
+        P = head_conv.out_channels
+        head_w = head_conv.weight.detach().to(dtype=torch.float32, device=x.data.device).reshape(P, -1).contiguous()
+        head_b = None if head_conv.bias is None else \
+            head_conv.bias.detach().to(dtype=torch.float32, device=x.data.device).contiguous()
+        return _ops.conv2d_b16_head_fwd(x.data, x.C, None if skip is None else skip.data, 0 if skip is None else skip.C,
+                                        st["w"], st["bias"], st["scale"], st["shift"], st["ap"], gate, head_w,
+                                        head_b, list(self.geom),
+                                        [int(self.transposed), int(self.act_code), 0, int(self.halves), int(head_act_code),
+                                         int(interleaved)])

@@ -43,6 +43,7 @@ typedef float b16_f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* b16_lds_ptr;
 typedef __bf16 b16_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float b16_f32x2 __attribute__((ext_vector_type(2)));
+typedef float b16_f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned b16_pack2(float lo, float hi) {        // v_cvt_pk_bf16_f32: nearest-even
     return __builtin_bit_cast(unsigned, __builtin_convertvector(b16_f32x2{lo, hi}, b16_bf16x2));
@@ -81,8 +82,14 @@ struct B16Args {
     int pair;                // 1: column tiles = the two column phases
     int in_buf_bytes, w_buf_bytes;
     int act, act_first, act_pc, out_nchw_f32;
+    // fused 1x1 head: out = head_act(head_w [P][K] . layer_output + head_b) per pixel, written as fp32 instead of the
+    // layer's own output (head_P = 0: no head).  head_il: [N][OH][OW][P] instead of [N][P][OH][OW].
+    const float* head_w; const float* head_b;
+    int head_P, head_act, head_il;
     B16Phase ph[kB16MaxPhase];
 };
+
+constexpr int kB16MaxHead = 4;        // output channels of a fused head
 
 // Activations.  LeakyReLU / PReLU / ReLU / none are one select with a per-channel slope (1 for none, 0 for
 // ReLU) and are what the wide layers use.  The transcendental ones go through a run-time switch, which
@@ -156,9 +163,15 @@ __device__ __forceinline__ void b16_wait_vm(int n) {
 // Bias, folded BatchNorm, activation and gate on the fp32 accumulators, then either 8-byte stores of
 // four bfloat16 channels (lanes l and l+32 complete a pixel's 16-byte record, a wave writes 512
 // contiguous bytes per instruction) or plain fp32 NCHW stores for the heads.
-template <int MT, int NT, bool GEN, bool PAIR>
+// FOLD: the prologue found the layer's per-channel arithmetic reducible to  act(acc * A + B)  with one slope for every
+// channel (bias and BatchNorm folded into A, B; a non-negative gate folded too, since act(z) * g = act(z * g) for
+// g >= 0 with a leaky / ReLU / identity activation): two 16-byte parameter reads per four channels instead of
+// twenty 4-byte ones -- a workgroup's eight waves otherwise spend more LDS cycles on parameters than on a
+// step's operands.  s_par rows then are A, B, -, slope, -.
+template <int MT, int NT, bool GEN, bool PAIR, bool FOLD>
 __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], const B16Args& p, const B16Phase& ph,
                                              const float* s_par, int n, int oh, int j0, int half, int j) {
+    static_assert(!(GEN && FOLD), "the folded form has leaky / ReLU / identity activations only");
     const int CBo = 2 * ((p.K + 15) >> 4);
     const size_t OHW = (size_t)p.OH * p.OW;
     size_t pix[NT];
@@ -169,31 +182,44 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
         ok[nt] = jc < ph.cols[PAIR ? nt : 0];
         pix[nt] = (size_t)oh * p.OW + (size_t)(jc * p.sow + ph.pow_[PAIR ? nt : 0]);
     }
+    const float slope0 = s_par[3 * MT * 32];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int blk = mt * 4 + q;
             const int m0 = blk * 8 + half * 4;
-            float bi[4], sc[4], sf[4], sl[4], gt[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bi[r] = s_par[m0 + r]; sc[r] = s_par[MT * 32 + m0 + r]; sf[r] = s_par[2 * MT * 32 + m0 + r];
-                sl[r] = s_par[3 * MT * 32 + m0 + r]; gt[r] = s_par[4 * MT * 32 + m0 + r];
-            }
             float v[NT][4];
+            if constexpr (FOLD) {
+                const b16_f32x4 A = *reinterpret_cast<const b16_f32x4*>(s_par + m0);
+                const b16_f32x4 B = *reinterpret_cast<const b16_f32x4*>(s_par + MT * 32 + m0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = fmaf(acc[mt][nt][q * 4 + r], A[r], B[r]);
+                        v[nt][r] = x >= 0.f ? x : x * slope0;
+                    }
+            } else {
+                float bi[4], sc[4], sf[4], sl[4], gt[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = acc[mt][nt][q * 4 + r] + bi[r];
-                    if (p.act_first) x = (GEN ? b16_act_general(x, p.act, sl[r]) : (x >= 0.f ? x : x * sl[r])) * sc[r] + sf[r];
-                    else {
-                        x = x * sc[r] + sf[r];
-                        x = GEN ? b16_act_general(x, p.act, sl[r]) : (x >= 0.f ? x : x * sl[r]);
-                    }
-                    v[nt][r] = x * gt[r];
+                    bi[r] = s_par[m0 + r]; sc[r] = s_par[MT * 32 + m0 + r]; sf[r] = s_par[2 * MT * 32 + m0 + r];
+                    sl[r] = s_par[3 * MT * 32 + m0 + r]; gt[r] = s_par[4 * MT * 32 + m0 + r];
                 }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = acc[mt][nt][q * 4 + r] + bi[r];
+                        if (p.act_first) x = (GEN ? b16_act_general(x, p.act, sl[r]) : (x >= 0.f ? x : x * sl[r])) * sc[r] + sf[r];
+                        else {
+                            x = x * sc[r] + sf[r];
+                            x = GEN ? b16_act_general(x, p.act, sl[r]) : (x >= 0.f ? x : x * sl[r]);
+                        }
+                        v[nt][r] = x * gt[r];
+                    }
+            }
             if (p.out_nchw_f32) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -221,6 +247,84 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
         }
 }
 
+// The layer's epilogue followed by a 1x1 convolution to at most four channels, on the fp32 values before they would
+// have been rounded for storage: a lane holds MT*16 of its pixel's channels (lanes l and l+32 the two halves), so
+// the head is MT*16 multiply-adds per output and lane and one exchange between the lane halves.  Lane half h then
+// applies the head's activation to outputs h and h+2 and stores them (fp32, planar or pixel-interleaved).
+template <int MT, int NT, bool PAIR, bool FOLD, int HP>
+__device__ __forceinline__ void b16_head_epilogue(const b16_f32x16 (&acc)[MT][NT], const B16Args& p, const B16Phase& ph,
+                                                  const float* s_par, int n, int oh, int j0, int half, int j) {
+    static_assert(HP == 2 || HP == kB16MaxHead, "head rows are read in pairs");
+    const size_t OHW = (size_t)p.OH * p.OW;
+    float sum[NT][HP];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pp = 0; pp < HP; ++pp) sum[nt][pp] = 0.f;
+    const float slope0 = s_par[3 * MT * 32];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m0 = (mt * 4 + q) * 8 + half * 4;
+            b16_f32x4 hw[HP];
+#pragma unroll
+            for (int pp = 0; pp < HP; ++pp) hw[pp] = *reinterpret_cast<const b16_f32x4*>(s_par + (5 + pp) * MT * 32 + m0);
+            b16_f32x4 P0 = *reinterpret_cast<const b16_f32x4*>(s_par + m0);
+            b16_f32x4 P1 = *reinterpret_cast<const b16_f32x4*>(s_par + MT * 32 + m0);
+            b16_f32x4 P2, P3, P4;
+            if constexpr (!FOLD) {
+                P2 = *reinterpret_cast<const b16_f32x4*>(s_par + 2 * MT * 32 + m0);
+                P3 = *reinterpret_cast<const b16_f32x4*>(s_par + 3 * MT * 32 + m0);
+                P4 = *reinterpret_cast<const b16_f32x4*>(s_par + 4 * MT * 32 + m0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float x;
+                    if constexpr (FOLD) {
+                        x = fmaf(acc[mt][nt][q * 4 + r], P0[r], P1[r]);
+                        x = x >= 0.f ? x : x * slope0;
+                    } else {
+                        x = acc[mt][nt][q * 4 + r] + P0[r];
+                        if (p.act_first) x = (x >= 0.f ? x : x * P3[r]) * P1[r] + P2[r];
+                        else {
+                            x = x * P1[r] + P2[r];
+                            x = x >= 0.f ? x : x * P3[r];
+                        }
+                        x *= P4[r];
+                    }
+#pragma unroll
+                    for (int pp = 0; pp < HP; ++pp) sum[nt][pp] = fmaf(x, hw[pp][r], sum[nt][pp]);
+                }
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int jc = PAIR ? j0 + j : j0 + nt * 32 + j;
+        const bool ok = jc < ph.cols[PAIR ? nt : 0];
+        const size_t pix = (size_t)oh * p.OW + (size_t)(jc * p.sow + ph.pow_[PAIR ? nt : 0]);
+#pragma unroll
+        for (int k = 0; k < HP / 2; ++k) {
+            // outputs 2k and 2k+1: the lower lanes finish output 2k, the upper lanes output 2k+1 -- each lane sends
+            // the partial sum the OTHER half needs and keeps the one it finishes itself.  (The exchange goes through
+            // ds_bpermute: with v_permlane32_swap the compiler folded the sum of the instruction's two results
+            // into twice the first one.)
+            const float send = half ? sum[nt][2 * k] : sum[nt][2 * k + 1];
+            const float keep = half ? sum[nt][2 * k + 1] : sum[nt][2 * k];
+            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((half ^ 1) * 32 + j) << 2,
+                                                                                      __builtin_bit_cast(int, send)));
+            const int pp = 2 * k + half;
+            if (!ok || pp >= p.head_P) continue;
+            float y = keep + recv + (p.head_b ? p.head_b[pp] : 0.f);
+            y = b16_act_general(y, p.head_act, 1.f);                  // slope 1: UNETMI_ACT_NONE is the identity
+            float* o = static_cast<float*>(p.out);
+            if (p.head_il) o[((size_t)n * OHW + pix) * p.head_P + pp] = y;
+            else o[((size_t)n * p.head_P + pp) * OHW + pix] = y;
+        }
+    }
+}
+
 // OCC2: built for two workgroups per CU (128 registers, LDS images <= 80 KB, input image <= 32 KB), so one
 // workgroup's prologue and epilogue run under the other's matrix loop.
 template <int MT, int NT, bool GEN, bool OCC2, bool PAIR>
@@ -235,7 +339,7 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     const int nin_buf = p.din + 1;
     char* const s_in = smem;
     char* const s_w = smem + nin_buf * p.in_buf_bytes;
-    float* const s_par = reinterpret_cast<float*>(s_w + p.wring * p.w_buf_bytes);     // [5][MT*32]
+    float* const s_par = reinterpret_cast<float*>(s_w + p.wring * p.w_buf_bytes);     // [5 (+ 4 with a head)][MT*32]
 
     // ---- this workgroup's phase and tile ----------------------------------------------
     unsigned bid = blockIdx.x;
@@ -334,17 +438,38 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     };
 
     // ---- prologue: epilogue parameters and the first steps' operands --------------------------
+    // Can this workgroup's epilogue take the folded form (see b16_epilogue)?  One slope for all channels, affine
+    // before the activation, and no negative gate value for this sample.
+    float gv = 1.f;
+    if (tid < p.K && p.gate) gv = p.gate[(size_t)n * p.K + tid];
+    int* const s_flag = reinterpret_cast<int*>(s_par + (5 + (p.head_P ? kB16MaxHead : 0)) * MT * 32);
+    if (tid == 0) *s_flag = 0;
+    __syncthreads();
+    if (gv < 0.f) *s_flag = 1;                          // every writer stores the same value
+    __syncthreads();
+    const bool neg_gate = __builtin_amdgcn_readfirstlane(*s_flag) != 0;
+    const bool fold = !GEN && !p.act_first && !p.act_pc && !neg_gate;
     if (tid < MT * 32) {
         float par[5] = {0.f, 0.f, 0.f, 0.f, 0.f};       // channels past K produce exact zeros
         if (tid < p.K) {
-            par[0] = p.bias[tid]; par[1] = p.scale[tid]; par[2] = p.shift[tid];
-            par[3] = p.act == UNETMI_ACT_NONE ? 1.f : 0.f;                   // slope of the select: none = 1, ReLU = 0
-            if (p.act == UNETMI_ACT_LEAKY) par[3] = p.act_param[p.act_pc ? tid : 0];
-            par[4] = p.gate ? p.gate[(size_t)n * p.K + tid] : 1.f;
+            float slope = p.act == UNETMI_ACT_NONE ? 1.f : 0.f;                  // slope of the select: none = 1, ReLU = 0
+            if (p.act == UNETMI_ACT_LEAKY) slope = p.act_param[p.act_pc ? tid : 0];
+            par[3] = slope;
+            if (fold) {
+                par[0] = p.scale[tid] * gv;
+                par[1] = (p.bias[tid] * p.scale[tid] + p.shift[tid]) * gv;
+            } else {
+                par[0] = p.bias[tid]; par[1] = p.scale[tid]; par[2] = p.shift[tid]; par[4] = gv;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 5; ++q) s_par[q * MT * 32 + tid] = par[q];
     }
+    if (p.head_P)
+        for (int i = tid; i < kB16MaxHead * MT * 32; i += 512) {
+            const int pp = i / (MT * 32), c = i - pp * (MT * 32);
+            s_par[5 * MT * 32 + i] = (pp < p.head_P && c < p.K) ? p.head_w[pp * p.K + c] : 0.f;
+        }
     for (int g = 0; g < p.din; ++g) issue_input(g);
     issue_weights(0);
     if (p.wring == 3) issue_weights(1);
@@ -473,7 +598,23 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     if ((B16_ABLATE & 4) && p.N >= 0) return;           // timing experiment: no epilogue
     if (i >= prow) return;                              // wave-uniform
     const int oh = i * p.soh + p.ph[a].poh;
-    b16_epilogue<MT, NT, GEN, PAIR>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
+    if constexpr (!GEN) {
+        if (p.head_P) {
+            if (p.head_P <= 2) {
+                if (fold) b16_head_epilogue<MT, NT, PAIR, true, 2>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
+                else b16_head_epilogue<MT, NT, PAIR, false, 2>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
+            } else {
+                if (fold) b16_head_epilogue<MT, NT, PAIR, true, kB16MaxHead>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
+                else b16_head_epilogue<MT, NT, PAIR, false, kB16MaxHead>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
+            }
+            return;
+        }
+        if (fold) {
+            b16_epilogue<MT, NT, false, PAIR, true>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
+            return;
+        }
+    }
+    b16_epilogue<MT, NT, GEN, PAIR, false>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
 }
 
 template <int MT, int NT, bool GEN>
@@ -548,7 +689,7 @@ static float host_bf16_to_f32(unsigned short b) {
     return v;
 }
 
-static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err) {
+static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err, int head_P = 0) {
     auto bad = [&](const char* m) { *err = m; return false; };
     if (d.N < 0 || d.C0 < 1 || d.C1 < 0 || d.H < 1 || d.W < 1 || d.K < 1 || d.kh < 1 || d.kw < 1 || d.sh < 1 || d.sw < 1 ||
         d.dh < 1 || d.dw < 1 || d.ph < 0 || d.pw < 0)
@@ -652,7 +793,7 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         const int rows_in = (kB16Waves - 1) * a.sih + (max_nth - 1) * std::abs(a.tdh) + 1;
         return (size_t)(((2 * rows_in * cols_in + 63) / 64) * 1024);
     };
-    const size_t par_bytes = 5 * pl->MT * 32 * 4;
+    const size_t par_bytes = (size_t)(5 + (head_P ? kB16MaxHead : 0)) * pl->MT * 32 * 4 + 16;   // + the prologue's flag word
     const bool general_act = d.act != UNETMI_ACT_NONE && d.act != UNETMI_ACT_LEAKY && d.act != UNETMI_ACT_RELU;
     bool found = false;
     for (int cc = allrows_ok ? 0 : 6; cc < 12 && !found; ++cc) {      // first with whole-group steps, then without
@@ -763,13 +904,14 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
     return UNETMI_OK;
 }
 
-int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
-                          const float* bias, const float* scale, const float* shift, const float* act_param,
-                          const float* gate, void* out, void* stream) {
+static int conv2d_b16_launch(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
+                             const float* bias, const float* scale, const float* shift, const float* act_param,
+                             const float* gate, const float* head_w, const float* head_b, int head_P, int head_act,
+                             int head_il, void* out, void* stream) {
     if (!d) return api_fail(UNETMI_E_BAD_ARG, "null descriptor");
     B16Plan pl;
     std::string err;
-    if (!make_b16_plan(*d, &pl, &err)) return api_fail(UNETMI_E_BAD_DESC, err);
+    if (!make_b16_plan(*d, &pl, &err, head_P)) return api_fail(UNETMI_E_BAD_DESC, err);
     if (d->N == 0) return UNETMI_OK;
     if (!in0 || !wpacked || !bias || !scale || !shift || !out) return api_fail(UNETMI_E_BAD_ARG, "null tensor pointer");
     if (d->in_mode == UNETMI_IN_CONCAT && !in1) return api_fail(UNETMI_E_BAD_ARG, "concat needs in1");
@@ -778,6 +920,7 @@ int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* 
     B16Args& a = pl.args;
     a.in0 = static_cast<const char*>(in0); a.in1 = static_cast<const char*>(in1); a.w = static_cast<const char*>(wpacked);
     a.bias = bias; a.scale = scale; a.shift = shift; a.act_param = act_param; a.gate = gate; a.out = out;
+    a.head_w = head_w; a.head_b = head_b; a.head_P = head_P; a.head_act = head_act; a.head_il = head_il;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipErrorInvalidConfiguration;
     const bool gen = d->act != UNETMI_ACT_NONE && d->act != UNETMI_ACT_LEAKY && d->act != UNETMI_ACT_RELU;
@@ -806,6 +949,28 @@ int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* 
 #undef UNETMI_B16
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("conv2d_b16 launch: ") + hipGetErrorString(e));
     return UNETMI_OK;
+}
+
+int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
+                          const float* bias, const float* scale, const float* shift, const float* act_param,
+                          const float* gate, void* out, void* stream) {
+    return conv2d_b16_launch(d, in0, in1, wpacked, bias, scale, shift, act_param, gate, nullptr, nullptr, 0,
+                             UNETMI_ACT_NONE, 0, out, stream);
+}
+
+int unetmi_conv2d_b16_head_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
+                               const float* bias, const float* scale, const float* shift, const float* act_param,
+                               const float* gate, const float* head_w, const float* head_b, int head_channels,
+                               int head_act, int interleaved, float* out, void* stream) {
+    if (head_channels < 1 || head_channels > kB16MaxHead)
+        return api_fail(UNETMI_E_UNSUPPORTED, "conv2d_b16_head: 1 to 4 head channels");
+    if (!head_w) return api_fail(UNETMI_E_BAD_ARG, "conv2d_b16_head: null head weights");
+    if (d && d->act != UNETMI_ACT_NONE && d->act != UNETMI_ACT_LEAKY && d->act != UNETMI_ACT_RELU)
+        return api_fail(UNETMI_E_UNSUPPORTED, "conv2d_b16_head: the layer's own activation must be none, LeakyReLU / PReLU or ReLU");
+    if (head_act < UNETMI_ACT_NONE || head_act > UNETMI_ACT_GELU || head_act == UNETMI_ACT_LEAKY)
+        return api_fail(UNETMI_E_BAD_DESC, "conv2d_b16_head: head activation must be none, ReLU, SiLU, Softplus, Sigmoid, Tanh or GELU");
+    return conv2d_b16_launch(d, in0, in1, wpacked, bias, scale, shift, act_param, gate, head_w, head_b, head_channels,
+                             head_act, interleaved ? 1 : 0, out, stream);
 }
 
 int unetmi_blocked_from_nchw(int N, int C, int HW, const void* src, int src_dtype, void* dst, void* stream) {

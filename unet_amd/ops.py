@@ -408,7 +408,10 @@ _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
 _LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
 _LIBRARY.define("conv2d_b16_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
                 "Tensor shift, Tensor? act_param, Tensor? gate, int[] geom, int[] flags) -> Tensor")
-# conv2d_wgrad flags = [transposed, in_mode]; conv2d_b16_fwd flags = [transposed, act, act_first, halves, nchw_out]
+_LIBRARY.define("conv2d_b16_head_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
+                "Tensor shift, Tensor? act_param, Tensor? gate, Tensor head_w, Tensor? head_b, int[] geom, int[] flags) -> Tensor")
+# conv2d_wgrad flags = [transposed, in_mode]; conv2d_b16_fwd flags = [transposed, act, act_first, halves, nchw_out];
+# conv2d_b16_head_fwd flags = [transposed, act, act_first, halves, head_act, interleaved]
 
 _ws_cache = {}
 
@@ -673,18 +676,21 @@ def b16_desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, has_gate
     return d
 
 
-def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, flags):
-    transposed, act, act_first, halves, nchw_out = flags
-    _dev(x, "x", "conv2d_b16_fwd", torch.bfloat16)
+def _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, transposed, act, act_first,
+                    halves, nchw_out, head):
+    """Checks shared by the two bf16-operand entry points, then the launch.  head: None, or (head_w [P,K], head_b
+    [P] | None, head_act, interleaved) for the decoder + 1x1 head launch."""
+    what = "conv2d_b16_fwd" if head is None else "conv2d_b16_head_fwd"
+    _dev(x, "x", what, torch.bfloat16)
     if x.dim() != 5 or x.shape[4] != 8 or x.shape[1] != blocks_for(C0):
-        raise ValueError("unetmi::conv2d_b16_fwd: x must be [N, 2*ceil(C0/16), H, W, 8] bfloat16")
+        raise ValueError("unetmi::{}: x must be [N, 2*ceil(C0/16), H, W, 8] bfloat16".format(what))
     N, _, H, W, _ = x.shape
     if skip is not None:
-        _dev(skip, "skip", "conv2d_b16_fwd", torch.bfloat16)
+        _dev(skip, "skip", what, torch.bfloat16)
         if skip.dim() != 5 or skip.shape[0] != N or tuple(skip.shape[2:4]) != (H, W) or skip.shape[1] != blocks_for(C1):
-            raise ValueError("unetmi::conv2d_b16_fwd: skip {} does not match x {}".format(tuple(skip.shape), tuple(x.shape)))
+            raise ValueError("unetmi::{}: skip {} does not match x {}".format(what, tuple(skip.shape), tuple(x.shape)))
     elif C1:
-        raise ValueError("unetmi::conv2d_b16_fwd: C1 without a skip tensor")
+        raise ValueError("unetmi::{}: C1 without a skip tensor".format(what))
     K = geom[0]
     act_pc = 1 if (act_param is not None and act_param.numel() > 1) else 0
     d = b16_desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, int(gate is not None), halves, nchw_out)
@@ -692,19 +698,30 @@ def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param
     if expect == 0:
         raise _lib.UnetmiError("conv2d_b16: " + _lib.last_error(), _lib.E_BAD_DESC)
     if not wpacked.is_cuda or wpacked.numel() * wpacked.element_size() != expect:
-        raise ValueError("unetmi::conv2d_b16_fwd: packed weight image has {} bytes, expected {} on the device".format(
-            wpacked.numel() * wpacked.element_size(), expect))
+        raise ValueError("unetmi::{}: packed weight image has {} bytes, expected {} on the device".format(
+            what, wpacked.numel() * wpacked.element_size(), expect))
     for t, name in ((bias, "bias"), (scale, "scale"), (shift, "shift")):
-        _dev(t, name, "conv2d_b16_fwd")
+        _dev(t, name, what)
         if tuple(t.shape) != (K,):
-            raise ValueError("unetmi::conv2d_b16_fwd: {} must be [K]".format(name))
+            raise ValueError("unetmi::{}: {} must be [K]".format(what, name))
     if act_param is not None:
-        _dev(act_param, "act_param", "conv2d_b16_fwd")
+        _dev(act_param, "act_param", what)
     if gate is not None:
-        _dev(gate, "gate", "conv2d_b16_fwd")
+        _dev(gate, "gate", what)
         if tuple(gate.shape) != (N, K):
-            raise ValueError("unetmi::conv2d_b16_fwd: gate must be [N,K]")
-    if nchw_out:
+            raise ValueError("unetmi::{}: gate must be [N,K]".format(what))
+    if head is not None:
+        head_w, head_b, head_act, interleaved = head
+        _dev(head_w, "head_w", what)
+        P = head_w.shape[0]
+        if head_w.dim() != 2 or head_w.shape[1] != K or not 1 <= P <= 4:
+            raise ValueError("unetmi::conv2d_b16_head_fwd: head_w must be [P, K] with 1 <= P <= 4")
+        if head_b is not None:
+            _dev(head_b, "head_b", what)
+            if tuple(head_b.shape) != (P,):
+                raise ValueError("unetmi::conv2d_b16_head_fwd: head_b must be [P]")
+        out = torch.empty((N, d.OH, d.OW, P) if interleaved else (N, P, d.OH, d.OW), dtype=torch.float32, device=x.device)
+    elif nchw_out:
         out = torch.empty((N, K, d.OH, d.OW), dtype=torch.float32, device=x.device)
     else:
         out = torch.empty((N, blocks_for(K), d.OH, d.OW, 8), dtype=torch.bfloat16, device=x.device)
@@ -713,13 +730,31 @@ def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param
         if obs is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        check(_lib.lib.unetmi_conv2d_b16_fwd(ctypes.byref(d), _ptr(x), _ptr(skip), _ptr(wpacked), _ptr(bias), _ptr(scale),
-                                             _ptr(shift), _ptr(act_param), _ptr(gate), _ptr(out), _stream(x)),
-              "unetmi_conv2d_b16_fwd")
+        if head is None:
+            check(_lib.lib.unetmi_conv2d_b16_fwd(ctypes.byref(d), _ptr(x), _ptr(skip), _ptr(wpacked), _ptr(bias),
+                                                 _ptr(scale), _ptr(shift), _ptr(act_param), _ptr(gate), _ptr(out),
+                                                 _stream(x)), "unetmi_conv2d_b16_fwd")
+        else:
+            check(_lib.lib.unetmi_conv2d_b16_head_fwd(ctypes.byref(d), _ptr(x), _ptr(skip), _ptr(wpacked), _ptr(bias),
+                                                      _ptr(scale), _ptr(shift), _ptr(act_param), _ptr(gate), _ptr(head_w),
+                                                      _ptr(head_b), P, int(head_act), int(interleaved), _ptr(out),
+                                                      _stream(x)), "unetmi_conv2d_b16_head_fwd")
         if obs is not None:
             ev1.record()
-            obs("conv2d_b16_fwd", d, ev0, ev1)
+            obs(what, d, ev0, ev1)
     return out
+
+
+def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, flags):
+    transposed, act, act_first, halves, nchw_out = flags
+    return _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, transposed, act, act_first,
+                           halves, nchw_out, None)
+
+
+def _conv2d_b16_head_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, head_w, head_b, geom, flags):
+    transposed, act, act_first, halves, head_act, interleaved = flags
+    return _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, transposed, act, act_first,
+                           halves, 0, (head_w, head_b, head_act, interleaved))
 
 
 for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_batch_stats", _bn_batch_stats_cuda),
@@ -727,7 +762,7 @@ for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_batch_stats", 
                    ("bn_act_bwd", _bn_act_bwd_cuda), ("conv2d_wgrad", _conv2d_wgrad_cuda),
                    ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda), ("gru_recurrence", _gru_recurrence_cuda), ("dwconv2d_wgrad", _dwconv2d_wgrad_cuda),
                    ("blocked_from_nchw", _blocked_from_nchw_cuda), ("nchw_from_blocked", _nchw_from_blocked_cuda),
-                   ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda)):
+                   ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda), ("conv2d_b16_head_fwd", _conv2d_b16_head_fwd_cuda)):
     _LIBRARY.impl(_name, _fn, "CUDA")
 
 
@@ -810,6 +845,15 @@ def _(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, flags
     return x.new_empty((N, blocks_for(K), OH, OW, 8))
 
 
+@torch.library.register_fake("unetmi::conv2d_b16_head_fwd")
+def _(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, head_w, head_b, geom, flags):
+    K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
+    N, _, H, W, _ = x.shape
+    OH, OW = conv_out_size(H, kh, sh, ph, dh, oph, flags[0]), conv_out_size(W, kw, sw, pw, dw, opw, flags[0])
+    P = head_w.shape[0]
+    return x.new_empty((N, OH, OW, P) if flags[5] else (N, P, OH, OW), dtype=torch.float32)
+
+
 bn_train_stats = torch.ops.unetmi.bn_train_stats
 bn_batch_stats = torch.ops.unetmi.bn_batch_stats
 bn_running_update = torch.ops.unetmi.bn_running_update
@@ -824,3 +868,4 @@ dwconv2d_wgrad = torch.ops.unetmi.dwconv2d_wgrad
 blocked_from_nchw = torch.ops.unetmi.blocked_from_nchw
 nchw_from_blocked = torch.ops.unetmi.nchw_from_blocked
 conv2d_b16_fwd = torch.ops.unetmi.conv2d_b16_fwd
+conv2d_b16_head_fwd = torch.ops.unetmi.conv2d_b16_head_fwd
