@@ -231,11 +231,13 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
                 // lanes l and l+32 hold the two halves of a pixel's record in each column tile: swapping the upper
                 // lanes of tile 0 with the lower lanes of tile 1 leaves every lane with one whole 16-byte record
                 // (lanes 0..31: tile 0, lanes 32..63: tile 1)
-                const auto lo = __builtin_amdgcn_permlane32_swap(b16_pack2(v[0][0], v[0][1]), b16_pack2(v[1][0], v[1][1]), false, false);
-                const auto hi = __builtin_amdgcn_permlane32_swap(b16_pack2(v[0][2], v[0][3]), b16_pack2(v[1][2], v[1][3]), false, false);
+                unsigned lo0 = b16_pack2(v[0][0], v[0][1]), lo1 = b16_pack2(v[1][0], v[1][1]);
+                unsigned hi0 = b16_pack2(v[0][2], v[0][3]), hi1 = b16_pack2(v[1][2], v[1][3]);
+                swap_lane_halves(lo0, lo1);
+                swap_lane_halves(hi0, hi1);
                 if ((half ? ok[1] : ok[0]) && blk < CBo) {
                     char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + (half ? pix[1] : pix[0])) * 16;
-                    *reinterpret_cast<uint4*>(o) = uint4{lo[0], hi[0], lo[1], hi[1]};
+                    *reinterpret_cast<uint4*>(o) = uint4{lo0, hi0, lo1, hi1};
                 }
             } else if (ok[0] && blk < CBo) {
                 uint2 w2;
@@ -307,9 +309,7 @@ __device__ __forceinline__ void b16_head_epilogue(const b16_f32x16 (&acc)[MT][NT
 #pragma unroll
         for (int k = 0; k < HP / 2; ++k) {
             // outputs 2k and 2k+1: the lower lanes finish output 2k, the upper lanes output 2k+1 -- each lane sends
-            // the partial sum the OTHER half needs and keeps the one it finishes itself.  (The exchange goes through
-            // ds_bpermute: with v_permlane32_swap the compiler folded the sum of the instruction's two results
-            // into twice the first one.)
+            // the partial sum the OTHER half needs and keeps the one it finishes itself (through ds_bpermute)
             const float send = half ? sum[nt][2 * k] : sum[nt][2 * k + 1];
             const float keep = half ? sum[nt][2 * k + 1] : sum[nt][2 * k];
             const float recv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((half ^ 1) * 32 + j) << 2,

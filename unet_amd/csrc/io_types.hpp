@@ -107,4 +107,12 @@ __device__ __forceinline__ void buf_st_act4(io_f32x4 v, __amdgpu_buffer_rsrc_t r
 
 template <bool BF16> constexpr int act_bytes() { return BF16 ? 2 : 4; }
 
+// Lanes [32, 64) of a and lanes [0, 32) of b change places (v_permlane32_swap_b32).  Written as inline assembly, with
+// the wait states around it that the compiler puts around its own: in some uses of __builtin_amdgcn_permlane32_swap
+// this compiler took the instruction's two results for one value (it added them as 2 * first, or stored the first
+// one twice and reused the second one's register).
+__device__ __forceinline__ void swap_lane_halves(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
 }  // namespace unetmi

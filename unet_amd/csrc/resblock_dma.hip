@@ -22,7 +22,7 @@
 //     buffer, and copies the running-add values of step s out of its patch,
 // then waits until its piece of the patch of step s+2 has landed (younger DMA groups stay in flight) and meets
 // the other waves at ONE barrier.  Steps run on across tiles; the epilogue (PReLU, BatchNorm affine, running
-// add, store: 128-byte runs) follows the barrier of a tile's last step.
+// add, store: one instruction = 64 consecutive pixels of one channel) follows the barrier of a tile's last step.
 //
 // Image borders: rows outside the image and 4-column groups that lie wholly outside it are range-check misses
 // of the DMA (zeros).  The left halo is padded to whole groups, so only the right border can cut a group: it then
@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
             const int q = i * 64 + lane;
             const int r = q / G::QPR, qc = q - r * G::QPR;
             const int grow = row0 - 1 + r, gc = col0 - G::DL + G::GE * qc;
-            const bool ok = (unsigned)grow < (unsigned)a.H && gc + G::GE - 1 >= 0 && gc < a.W;
+            bool ok = (unsigned)grow < (unsigned)a.H && gc + G::GE - 1 >= 0 && gc < a.W;
+            if (RB_OFF(128) && (r == 0 || r == G::PROWS - 1)) ok = false;                    // timing: no halo rows
+            if (RB_OFF(256) && (gc < col0 || gc + G::GE > col0 + G::TC)) ok = false;         // timing: no halo columns
             toff[i] = ok ? (grow * a.W + gc) * EB : kRbSentinel;
         }
     };
@@ -369,25 +371,27 @@ __global__ __launch_bounds__(256, 2) void resblock_dma_kernel(const ResblockArgs
             const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(a.out) + (size_t)n * kRbC * HW * EB, 0,
                                                                   RB_OFF(8) ? 0 : kRbC * HW * EB, 0x00020000);
             const int orow = row0 + wave;
-            int obase[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int ocol = col0 + h * 32 + j;
-                obase[h] = (orow < a.H && ocol < a.W) ? ((4 * half) * HW + orow * a.W + ocol) * EB : kRbSentinel;
-            }
+            // one store instruction = 64 consecutive pixels of ONE channel (256 contiguous bytes): the lower lanes'
+            // pixels 32..63 and the upper lanes' pixels 0..31 change places first
+            const int ocol64 = col0 + lane;
+            const int obase64 = (orow < a.H && ocol64 < a.W) ? (orow * a.W + ocol64) * EB : kRbSentinel;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cou = t * 32 + (r & 3) + 8 * (r >> 2);
                     const float sc = s_par[kRbC + cou + 4 * half], sh = s_par[2 * kRbC + cou + 4 * half];
+                    float v[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        float v = acc[t][h][r];
-                        v = fmaf(fminf(v, 0.f), alpha_m1, v);
-                        v = fmaf(v, sc, sh) + res[t][h][r];
-                        buf_st_act<BF16>(v, rs_out, obase[h], cou * HW * EB);
+                        float x = acc[t][h][r];
+                        x = fmaf(fminf(x, 0.f), alpha_m1, x);
+                        v[h] = fmaf(x, sc, sh) + res[t][h][r];
                     }
+                    unsigned s0 = __builtin_bit_cast(unsigned, v[0]), s1 = __builtin_bit_cast(unsigned, v[1]);
+                    swap_lane_halves(s0, s1);          // s0: channel cou, s1: channel cou + 4, pixel = lane in both
+                    buf_st_act<BF16>(__builtin_bit_cast(float, s0), rs_out, obase64, cou * HW * EB);
+                    buf_st_act<BF16>(__builtin_bit_cast(float, s1), rs_out, obase64, (cou + 4) * HW * EB);
                 }
         }
         if (!has_next) break;
