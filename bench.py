@@ -88,6 +88,13 @@ def conv_macs(d):
     return d.N * d.OH * d.OW * d.K * cin * d.kh * d.kw
 
 
+def conv_bytes(d):
+    """Algorithmic HBM bytes of one fused conv launch: every input element read once, every output element
+    written once (fp32), weights and per-channel parameters neglected."""
+    cin = d.C0 + (d.C1 if d.in_mode == 1 else 0)
+    return 4 * d.N * (cin * d.H * d.W + d.K * d.OH * d.OW)
+
+
 def kernel_variant(d):
     """Name of the kernel instantiation that serves this layer, as rocprofv3 prints it: asked of the library
     (unetmi_conv2d_kernel_name), whose plan picks the instantiation from the geometry AND the grid size."""
@@ -337,7 +344,7 @@ def main():
         records = []
         shapes = []
         ops.set_launch_observer(lambda name, d, e0, e1: (records.append(
-            (kernel_variant(d), conv_macs(d), e0, e1)), shapes.append(
+            (kernel_variant(d), conv_macs(d), e0, e1, conv_bytes(d))), shapes.append(
             "{}{}+{}->{} k{}x{} s{}x{} out {}x{}".format("T" if d.transposed else "C", d.C0, d.C1, d.K,
                                                       d.kh, d.kw, d.sh, d.sw, d.OH, d.OW))))
         barrier()
@@ -357,19 +364,20 @@ def main():
 
     if rank == 0 and args.layers:
         per_step = len(records) // args.steps
-        for (variant, macs, e0, e1), shape in zip(records[-per_step:], shapes[-per_step:]):
+        for (variant, macs, e0, e1, _), shape in zip(records[-per_step:], shapes[-per_step:]):
             ms = e0.elapsed_time(e1)
             print("{:42s} {:34s} {:8.3f} ms {:7.1f} TFLOP/s".format(
                 shape, variant, ms, 2e-9 * macs / ms), file=sys.stderr)
     if rank == 0:
         per_variant = {}
-        for variant, macs, e0, e1 in records:
-            acc = per_variant.setdefault(variant, [0.0, 0.0, 0])
+        for variant, macs, e0, e1, nbytes in records:
+            acc = per_variant.setdefault(variant, [0.0, 0.0, 0, 0.0])
             acc[0] += 2.0 * macs
             acc[1] += e0.elapsed_time(e1) * 1e-3
             acc[2] += 1
+            acc[3] += nbytes
         dominant = max(per_variant, key=lambda k: per_variant[k][1])
-        flops, secs, launches = per_variant[dominant]
+        flops, secs, launches, algo_bytes = per_variant[dominant]
         achieved = flops / secs / 1e12
         result = {
             "metric": "audio-seconds processed/sec (whole node), UNet fwd fp32",
@@ -391,6 +399,7 @@ def main():
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(dominant),
                          "launches": launches, "avg_launch_ms": 1e3 * secs / launches,
                          "gflop_per_launch": flops / launches / 1e9,
+                         "algorithmic_bytes_per_launch": algo_bytes / launches,
                          "all_kernels": {k: {"tflops": v[0] / v[1] / 1e12, "ms": 1e3 * v[1] / args.steps,
                                              "launches_per_step": v[2] // args.steps}
                                          for k, v in per_variant.items()}},
