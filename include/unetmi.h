@@ -296,10 +296,10 @@ int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* 
  * (DSUNet.py:616-628 with CRM.forward :355-359: decoder -> Conv2d(C, 2, 1) -> tanh / sigmoid / softplus): the
  * decoder's result stays in the fp32 accumulators (it is never rounded or written), and per pixel
  *   out[p] = head_act(sum_k head_w[p][k] * decoder_out[k] + head_b[p]),   p < head_channels <= 4.
- * head_w [head_channels][K] fp32, head_b [head_channels] or null, head_act = UNETMI_ACT_* (not LeakyReLU).
+ * head_w [head_channels][K] fp32, head_b [head_channels] or null, head_act = UNETMI_ACT_* (not LeakyReLU, not GELU).
  * out: fp32 [N][head_channels][OH][OW], or with interleaved != 0 [N][OH][OW][head_channels] (two channels that
  * way are a complex64 [N][OH][OW] tensor, which is what the reference's CRM head returns).  The descriptor's
- * reserved[2] is ignored. */
+ * reserved[2] is ignored.  Not built for time-stride-2 transposed layers (UNETMI_E_BAD_DESC). */
 int unetmi_conv2d_b16_head_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
                                const float* bias, const float* scale, const float* shift, const float* act_param,
                                const float* gate, const float* head_w, const float* head_b, int head_channels,

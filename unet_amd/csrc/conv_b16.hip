@@ -107,6 +107,19 @@ __device__ __forceinline__ float b16_act_general(float v, int act, float slope) 
     }
 }
 
+// The squash of a fused head: the activations built from v_exp / v_log / v_rcp only (no GELU: erff is a long
+// polynomial with branches).
+__device__ __forceinline__ float b16_head_act(float v, int act) {
+    switch (act) {
+        case UNETMI_ACT_RELU:     return fmaxf(v, 0.f);
+        case UNETMI_ACT_SILU:     return v * fast_sigmoid(v);
+        case UNETMI_ACT_SOFTPLUS: return fast_softplus(v);
+        case UNETMI_ACT_SIGMOID:  return fast_sigmoid(v);
+        case UNETMI_ACT_TANH:     return fast_tanh(v);
+        default:                  return v;
+    }
+}
+
 // f(integral_constant<int, I>) for I = FROM .. TO-1 with I a compile-time value
 template <int FROM, int TO, class F>
 __device__ __forceinline__ void static_for_b16(F&& f) {
@@ -269,6 +282,7 @@ __device__ __forceinline__ void b16_head_epilogue(const b16_f32x16 (&acc)[MT][NT
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int m0 = (mt * 4 + q) * 8 + half * 4;
+            __builtin_amdgcn_sched_barrier(0);          // one channel quad at a time: keeps the parameter reads of later quads out of the registers
             b16_f32x4 hw[HP];
 #pragma unroll
             for (int pp = 0; pp < HP; ++pp) hw[pp] = *reinterpret_cast<const b16_f32x4*>(s_par + (5 + pp) * MT * 32 + m0);
@@ -317,7 +331,7 @@ __device__ __forceinline__ void b16_head_epilogue(const b16_f32x16 (&acc)[MT][NT
             const int pp = 2 * k + half;
             if (!ok || pp >= p.head_P) continue;
             float y = keep + recv + (p.head_b ? p.head_b[pp] : 0.f);
-            y = b16_act_general(y, p.head_act, 1.f);                  // slope 1: UNETMI_ACT_NONE is the identity
+            y = b16_head_act(y, p.head_act);
             float* o = static_cast<float*>(p.out);
             if (p.head_il) o[((size_t)n * OHW + pix) * p.head_P + pp] = y;
             else o[((size_t)n * p.head_P + pp) * OHW + pix] = y;
@@ -598,7 +612,9 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     if ((B16_ABLATE & 4) && p.N >= 0) return;           // timing experiment: no epilogue
     if (i >= prow) return;                              // wave-uniform
     const int oh = i * p.soh + p.ph[a].poh;
-    if constexpr (!GEN) {
+    if constexpr (!GEN && NT == 1 && !PAIR) {
+        // the fused head exists in the one-column-tile kernels only (the plan gives a layer with a head one of them):
+        // four more epilogue bodies in every two-tile kernel made the compiler spill hundreds of registers there
         if (p.head_P) {
             if (p.head_P <= 2) {
                 if (fold) b16_head_epilogue<MT, NT, PAIR, true, 2>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
@@ -609,6 +625,8 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
             }
             return;
         }
+    }
+    if constexpr (!GEN) {
         if (fold) {
             b16_epilogue<MT, NT, false, PAIR, true>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
             return;
@@ -760,6 +778,7 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
             }
     }
     a.nphase = np;
+    if (head_P && a.pair) return bad("conv2d_b16_head: not built for time-stride-2 transposed layers");
     // Tile shape and pipeline depth.  Preference: two workgroups per CU (weight ring of 2, LDS <= 80 KB each,
     // one workgroup's prologue / epilogue hidden under the other's matrix loop) with two column tiles, then with
     // one; else one workgroup per CU with a ring of 3.  A step takes every tap row of a channel group when
@@ -806,6 +825,7 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         const bool shallow = c >= 4;
         if (nt == 2 && pl->MT > 3) continue;
         if (a.pair && nt != 2) continue;
+        if (head_P && nt != 1) continue;            // the fused head is built into the one-column-tile kernels
         if (occ2 && general_act) continue;
         const size_t ib = in_bytes(nt);
         const int din = (occ2 || shallow) ? 1 : (single_step_group ? 2 : 1);
@@ -967,8 +987,8 @@ int unetmi_conv2d_b16_head_fwd(const UnetmiConvDesc* d, const void* in0, const v
     if (!head_w) return api_fail(UNETMI_E_BAD_ARG, "conv2d_b16_head: null head weights");
     if (d && d->act != UNETMI_ACT_NONE && d->act != UNETMI_ACT_LEAKY && d->act != UNETMI_ACT_RELU)
         return api_fail(UNETMI_E_UNSUPPORTED, "conv2d_b16_head: the layer's own activation must be none, LeakyReLU / PReLU or ReLU");
-    if (head_act < UNETMI_ACT_NONE || head_act > UNETMI_ACT_GELU || head_act == UNETMI_ACT_LEAKY)
-        return api_fail(UNETMI_E_BAD_DESC, "conv2d_b16_head: head activation must be none, ReLU, SiLU, Softplus, Sigmoid, Tanh or GELU");
+    if (head_act < UNETMI_ACT_NONE || head_act >= UNETMI_ACT_GELU || head_act == UNETMI_ACT_LEAKY)
+        return api_fail(UNETMI_E_BAD_DESC, "conv2d_b16_head: head activation must be none, ReLU, SiLU, Softplus, Sigmoid or Tanh");
     return conv2d_b16_launch(d, in0, in1, wpacked, bias, scale, shift, act_param, gate, head_w, head_b, head_channels,
                              head_act, interleaved ? 1 : 0, out, stream);
 }
