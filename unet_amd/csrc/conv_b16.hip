@@ -341,9 +341,16 @@ __device__ __forceinline__ void b16_head_epilogue(const b16_f32x16 (&acc)[MT][NT
 
 // OCC2: built for two workgroups per CU (128 registers, LDS images <= 80 KB, input image <= 32 KB), so one
 // workgroup's prologue and epilogue run under the other's matrix loop.
-template <int MT, int NT, bool GEN, bool OCC2, bool PAIR>
+//
+// RT: output rows per wave.  With RT = 2 a wave owns rows w and w + 8 of a 16-row workgroup tile: MT x (RT*NT)
+// accumulator tiles, so a tap's MT weight operands serve RT*NT pixel operands (MT = 3, NT = 2: 7 LDS reads per 12
+// MFMAs instead of 5 per 6 -- 0.58 KB of LDS reads per MFMA against a budget of 1 KB at the matrix peak) and the
+// input rows of the taps' halo are shared by twice as many output rows.  One workgroup per CU (192 accumulators).
+template <int MT, int NT, bool GEN, bool OCC2, bool PAIR, int RT = 1>
 __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     static_assert(!PAIR || NT == 2, "pair mode uses both column tiles");
+    static_assert(RT == 1 || (!OCC2 && !GEN && NT == 2), "two rows per wave: the one-workgroup-per-CU two-tile kernels only");
+    constexpr int WROWS = kB16Waves * RT;               // phase-grid rows of a workgroup tile
     constexpr int MAXQ = OCC2 ? kB16MaxQ / 2 : kB16MaxQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -367,15 +374,15 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     const int nth = p.ph[a].nth, ntw0 = p.ph[a].ntw[0], ntw1 = p.ph[a].ntw[1];
     const int ntws = PAIR ? ntw0 + ntw1 : ntw0;         // taps per tap row in the weight image
     const int prow = p.ph[a].rows;
-    const int njt = (p.ph[a].cols[0] + TW - 1) / TW, nit = (prow + kB16Waves - 1) / kB16Waves;
+    const int njt = (p.ph[a].cols[0] + TW - 1) / TW, nit = (prow + WROWS - 1) / WROWS;
     const int jt = bid % njt; bid /= njt;
     const int it = bid % nit;
     const int n = bid / nit;
-    const int i0 = it * kB16Waves, j0 = jt * TW;
+    const int i0 = it * WROWS, j0 = jt * TW;
 
     const int spanh = (nth - 1) * p.tdh;
     const int negh = spanh < 0 ? spanh : 0;
-    const int rows_in = (kB16Waves - 1) * p.sih + (spanh < 0 ? -spanh : spanh) + 1;
+    const int rows_in = (WROWS - 1) * p.sih + (spanh < 0 ? -spanh : spanh) + 1;
     // columns of the input image: the union of what the column tiles read
     int wbase, wtop;
     {
@@ -489,13 +496,15 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     if (p.wring == 3) issue_weights(1);
     __syncthreads();                                   // full drain once
 
-    b16_f32x16 acc[MT][NT];
+    b16_f32x16 acc[RT][MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][mt][nt][r] = 0.f;
 
     int colb[NT];
 #pragma unroll
@@ -503,9 +512,12 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
         colb[nt] = ((PAIR ? j : nt * 32 + j) * p.siw + p.ph[a].offw[PAIR ? nt : 0] - wbase) * 16;
     // per-lane LDS byte addresses: this lane's slot of a weight operand, and its pixel of an input image's first row
     const int la = b16_lds_addr(s_w) + half * 512 + j * 16;
-    int lb[NT];
+    int lb[RT][NT];                                    // row tile rt: 8 phase-grid rows = 8 * sih input rows further down
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) lb[nt] = b16_lds_addr(s_in) + half * plane * 16 + colb[nt];
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            lb[rt][nt] = b16_lds_addr(s_in) + half * plane * 16 + colb[nt] + rt * kB16Waves * p.sih * cols_in * 16;
 
     int s = 0;
     for (int g = 0; g < G; ++g) {
@@ -533,7 +545,9 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
                         constexpr int nt = decltype(nt_tag)::value;
                         const int cnt = nt ? ntw1 : ntw0;
                         int ub = b16_keep_scalar(ub0 + tr * rowstep);
-                        bf16x8 A[2], B = b16_lds_ld(lb[nt], ub, 0);
+                        bf16x8 A[2], B[RT];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) B[rt] = b16_lds_ld(lb[rt][nt], ub, 0);
                         A[0] = b16_lds_ld(la, uw, 0);
                         auto tap = [&](auto par_tag, bool more) {
                             constexpr int PAR = decltype(par_tag)::value;
@@ -543,11 +557,16 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
                                 if (mt + 1 < MT) A[cur ^ 1] = b16_lds_ld(la, uw, (mt + 1) * 1024);
                                 else if (more) A[cur ^ 1] = b16_lds_ld(la, uw, MT * 1024);
                                 __builtin_amdgcn_sched_barrier(0);      // the read goes out BEFORE the MFMAs it hides under
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur], B, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                                for (int rt = 0; rt < RT; ++rt)
+                                    acc[rt][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur], B[rt], acc[rt][mt][nt], 0, 0, 0);
                             }
                             uw = b16_keep_scalar(uw + MT * 1024);
                             ub = b16_keep_scalar(ub + tdw16);
-                            if (more) B = b16_lds_ld(lb[nt], ub, 0);
+                            if (more) {
+#pragma unroll
+                                for (int rt = 0; rt < RT; ++rt) B[rt] = b16_lds_ld(lb[rt][nt], ub, 0);
+                            }
                         };
                         int u = 0;
                         for (; u + 1 < cnt; u += 2) {
@@ -566,9 +585,11 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
                         if (++twn == ntw0) { twn = 0; nb += rowstep - ntw0 * tdw16; }
                         ub = b16_keep_scalar(nb);
                     };
-                    bf16x8 A[2], B[NT];
+                    bf16x8 A[2], B[RT][NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) B[nt] = b16_lds_ld(lb[nt], ub, 0);
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) B[rt][nt] = b16_lds_ld(lb[rt][nt], ub, 0);
                     A[0] = b16_lds_ld(la, uw, 0);
                     next_ub();
                     auto tap = [&](auto par_tag, bool more) {
@@ -580,12 +601,16 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
                             else if (more) A[cur ^ 1] = b16_lds_ld(la, uw, MT * 1024);
                             __builtin_amdgcn_sched_barrier(0);          // the read goes out BEFORE the MFMAs it hides under
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur], B[nt], acc[mt][nt], 0, 0, 0);
+                            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[rt][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur], B[rt][nt], acc[rt][mt][nt], 0, 0, 0);
                         }
                         if (more) {
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) B[nt] = b16_lds_ld(lb[nt], ub, 0);
+                            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) B[rt][nt] = b16_lds_ld(lb[rt][nt], ub, 0);
                         }
                         uw = b16_keep_scalar(uw + MT * 1024);
                         next_ub();
@@ -608,31 +633,34 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
-    const int i = i0 + wave;
     if ((B16_ABLATE & 4) && p.N >= 0) return;           // timing experiment: no epilogue
-    if (i >= prow) return;                              // wave-uniform
-    const int oh = i * p.soh + p.ph[a].poh;
-    if constexpr (!GEN && NT == 1 && !PAIR) {
-        // the fused head exists in the one-column-tile kernels only (the plan gives a layer with a head one of them):
-        // four more epilogue bodies in every two-tile kernel made the compiler spill hundreds of registers there
-        if (p.head_P) {
-            if (p.head_P <= 2) {
-                if (fold) b16_head_epilogue<MT, NT, PAIR, true, 2>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
-                else b16_head_epilogue<MT, NT, PAIR, false, 2>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
-            } else {
-                if (fold) b16_head_epilogue<MT, NT, PAIR, true, kB16MaxHead>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
-                else b16_head_epilogue<MT, NT, PAIR, false, kB16MaxHead>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
+    static_for_b16<0, RT>([&](auto rt_tag) {
+        constexpr int rt = decltype(rt_tag)::value;     // compile-time: names accumulator registers
+        const int i = i0 + rt * kB16Waves + wave;
+        if (i >= prow) return;                          // wave-uniform
+        const int oh = i * p.soh + p.ph[a].poh;
+        if constexpr (!GEN && NT == 1 && !PAIR) {
+            // the fused head exists in the one-column-tile kernels only (the plan gives a layer with a head one of
+            // them): four more epilogue bodies in every two-tile kernel made the compiler spill hundreds of registers
+            if (p.head_P) {
+                if (p.head_P <= 2) {
+                    if (fold) b16_head_epilogue<MT, NT, PAIR, true, 2>(acc[rt], p, p.ph[a], s_par, n, oh, j0, half, j);
+                    else b16_head_epilogue<MT, NT, PAIR, false, 2>(acc[rt], p, p.ph[a], s_par, n, oh, j0, half, j);
+                } else {
+                    if (fold) b16_head_epilogue<MT, NT, PAIR, true, kB16MaxHead>(acc[rt], p, p.ph[a], s_par, n, oh, j0, half, j);
+                    else b16_head_epilogue<MT, NT, PAIR, false, kB16MaxHead>(acc[rt], p, p.ph[a], s_par, n, oh, j0, half, j);
+                }
+                return;
             }
-            return;
         }
-    }
-    if constexpr (!GEN) {
-        if (fold) {
-            b16_epilogue<MT, NT, false, PAIR, true>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
-            return;
+        if constexpr (!GEN) {
+            if (fold) {
+                b16_epilogue<MT, NT, false, PAIR, true>(acc[rt], p, p.ph[a], s_par, n, oh, j0, half, j);
+                return;
+            }
         }
-    }
-    b16_epilogue<MT, NT, GEN, PAIR, false>(acc, p, p.ph[a], s_par, n, oh, j0, half, j);
+        b16_epilogue<MT, NT, GEN, PAIR, false>(acc[rt], p, p.ph[a], s_par, n, oh, j0, half, j);
+    });
 }
 
 template <int MT, int NT, bool GEN>
@@ -646,6 +674,13 @@ __global__ __launch_bounds__(512, 2) void conv_b16_kernel_pair(const B16Args p) 
 
 template <int MT>
 __global__ __launch_bounds__(512, 4) void conv_b16_kernel_pair_occ2(const B16Args p) { conv_b16_body<MT, 2, false, true, true>(p); }
+
+// two output rows per wave (16-row workgroup tiles), two column tiles / the two column phases
+template <int MT>
+__global__ __launch_bounds__(512, 2) void conv_b16_kernel_rt2(const B16Args p) { conv_b16_body<MT, 2, false, false, false, 2>(p); }
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void conv_b16_kernel_pair_rt2(const B16Args p) { conv_b16_body<MT, 2, false, false, true, 2>(p); }
 
 // ---- layout conversion ------------------------------------------------------------------------
 // NCHW (fp32 or bfloat16) -> blocked; a thread owns one pixel of one 8-channel block.
@@ -685,7 +720,7 @@ __global__ __launch_bounds__(256) void from_blocked_kernel(const char* src, void
 // ---- host: plan, packer, launch ---------------------------------------------------------------
 struct B16Plan {
     B16Args args;
-    int MT, NT;
+    int MT, NT, RT;
     bool occ2;
     unsigned grid;
     int kw0[kB16MaxPhase][2];
@@ -797,7 +832,7 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         wg64 += (unsigned long long)d.N * ((a.ph[q].rows + kB16Waves - 1) / kB16Waves) * ((a.ph[q].cols[0] + 63) / 64);
     const bool few_wg = wg64 <= 512;
     const bool allrows_ok = max_nth > 1 && max_nth * max_ntws * pl->MT <= (few_wg ? 48 : 24);
-    auto in_bytes = [&](int nt) {                  // largest input image of a channel group over the phases
+    auto in_bytes = [&](int nt, int rt = 1) {      // largest input image of a channel group over the phases
         const int tw_cols = a.pair ? 32 : 32 * nt;
         int cols_in = 1;
         for (int q = 0; q < np; ++q) {
@@ -809,12 +844,13 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
             }
             cols_in = std::max(cols_in, hi - lo + 1);
         }
-        const int rows_in = (kB16Waves - 1) * a.sih + (max_nth - 1) * std::abs(a.tdh) + 1;
+        const int rows_in = (kB16Waves * rt - 1) * a.sih + (max_nth - 1) * std::abs(a.tdh) + 1;
         return (size_t)(((2 * rows_in * cols_in + 63) / 64) * 1024);
     };
     const size_t par_bytes = (size_t)(5 + (head_P ? kB16MaxHead : 0)) * pl->MT * 32 * 4 + 16;   // + the prologue's flag word
     const bool general_act = d.act != UNETMI_ACT_NONE && d.act != UNETMI_ACT_LEAKY && d.act != UNETMI_ACT_RELU;
     bool found = false;
+    pl->RT = 1;
     for (int cc = allrows_ok ? 0 : 6; cc < 12 && !found; ++cc) {      // first with whole-group steps, then without
         const int c = cc % 6;                       // 4, 5: one workgroup per CU with rings of 2 (large steps)
         a.allrows = cc < 6 ? 1 : 0;
@@ -837,6 +873,39 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         pl->NT = nt; pl->occ2 = occ2; a.din = din; a.wring = wring; a.in_buf_bytes = (int)ib; pl->lds_bytes = lds;
         found = true;
     }
+    // Two output rows per wave (16-row workgroup tiles, one workgroup per CU: with MT = 3, 7 LDS operand reads per 12
+    // MFMAs instead of 5 per 6 or 4 per 3, and a shorter halo).  Measured per layer at batch 32 (tools/b16_probe.py with
+    // UNETMI_B16_RT = 1 / 2): it pays where the regular choice is a one-column-tile kernel (a (7,1) layer over 135
+    // channels 982 -> 849 us) and, slightly, on time-stride-2 transposed layers with three channel tiles (1429 ->
+    // 1391 us); two-column-tile layers with two resident workgroups lose 6 % to it, so they keep the regular plan.
+    // UNETMI_B16_RT = 1 / 2 (developer A/B switch, read once): never / wherever the images fit.
+    static const int rt_mode = [] { const char* e = std::getenv("UNETMI_B16_RT"); return e ? std::atoi(e) : 0; }();
+    if (rt_mode != 1 && !head_P && !general_act && pl->MT <= 3 &&
+        (rt_mode == 2 || (pl->MT == 3 && (a.pair || (found && pl->NT == 1))))) {
+        int min_rows = 1 << 30;
+        unsigned long long wg_rt = 0;
+        for (int q = 0; q < np; ++q) {
+            min_rows = std::min(min_rows, a.ph[q].rows);
+            wg_rt += (unsigned long long)d.N * ((a.ph[q].rows + 2 * kB16Waves - 1) / (2 * kB16Waves)) *
+                     ((a.ph[q].cols[0] + (a.pair ? 31 : 63)) / (a.pair ? 32 : 64));
+        }
+        const size_t ib = in_bytes(2, 2);
+        bool taken = false;
+        if ((rt_mode == 2 || (min_rows >= 2 * kB16Waves && wg_rt >= 512)) && ib <= (size_t)kB16MaxQ * kB16Waves * 1024) {
+            for (int ar = allrows_ok ? 1 : 0; ar >= 0 && !taken; --ar) {
+                const int wbuf = (ar ? max_nth : 1) * max_ntws * pl->MT * 1024;
+                const bool single_step_group = (ar || one_row_phase) && hl == 1;
+                for (int din = single_step_group ? 2 : 1; din >= 1 && !taken; --din) {
+                    const size_t lds = (size_t)(din + 1) * ib + (size_t)3 * wbuf + par_bytes;
+                    if (lds > 160 * 1024) continue;
+                    a.allrows = ar; a.w_buf_bytes = wbuf;
+                    pl->NT = 2; pl->RT = 2; pl->occ2 = false; a.din = din; a.wring = 3; a.in_buf_bytes = (int)ib;
+                    pl->lds_bytes = lds;
+                    taken = found = true;
+                }
+            }
+        }
+    }
     if (!found) return bad("conv2d_b16: LDS images exceed 160 KB");
     // weight image and grid
     const int G = a.G0 + a.G1;
@@ -849,7 +918,8 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         p.w_bytes = (unsigned)((size_t)G * p.nth * ntws * hl * pl->MT * 1024);
         woff += p.w_bytes;
         const int tw_cols = a.pair ? 32 : 32 * pl->NT;
-        const unsigned long long njt = (p.cols[0] + tw_cols - 1) / tw_cols, nit = (p.rows + kB16Waves - 1) / kB16Waves;
+        const int wrows = kB16Waves * pl->RT;
+        const unsigned long long njt = (p.cols[0] + tw_cols - 1) / tw_cols, nit = (p.rows + wrows - 1) / wrows;
         wg += njt * nit * (unsigned long long)d.N;
         p.wg_end = (unsigned)wg;
     }
@@ -947,16 +1017,21 @@ static int conv2d_b16_launch(const UnetmiConvDesc* d, const void* in0, const voi
     if (gen && (pl.MT > 1 || pl.args.pair))
         return api_fail(UNETMI_E_UNSUPPORTED, "conv2d_b16: SiLU / Softplus / Sigmoid / Tanh / GELU epilogues are built for K <= 32 "
                                               "and not for time-stride-2 transposed layers");
+#define UNETMI_B16_RT2(MT_)                                                                                 \
+    if (pl.RT == 2 && !pl.args.pair && pl.MT == MT_) {                                                      \
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_rt2<MT_>, &raised, pl, st); }           \
+    if (pl.RT == 2 && pl.args.pair && pl.MT == MT_) {                                                       \
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair_rt2<MT_>, &raised, pl, st); }
 #define UNETMI_B16(MT_, NT_, GEN_)                                                                          \
-    if (!pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && gen == GEN_ && !pl.occ2) {                         \
+    if (pl.RT == 1 && !pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && gen == GEN_ && !pl.occ2) {           \
         static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel<MT_, NT_, GEN_>, &raised, pl, st); }
 #define UNETMI_B16_OCC2(MT_, NT_)                                                                           \
-    if (!pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && !gen && pl.occ2) {                                 \
+    if (pl.RT == 1 && !pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && !gen && pl.occ2) {                   \
         static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_occ2<MT_, NT_>, &raised, pl, st); }
 #define UNETMI_B16_PAIR(MT_)                                                                                \
-    if (pl.args.pair && pl.MT == MT_ && !pl.occ2) {                                                         \
+    if (pl.RT == 1 && pl.args.pair && pl.MT == MT_ && !pl.occ2) {                                           \
         static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair<MT_>, &raised, pl, st); }          \
-    if (pl.args.pair && pl.MT == MT_ && pl.occ2) {                                                          \
+    if (pl.RT == 1 && pl.args.pair && pl.MT == MT_ && pl.occ2) {                                            \
         static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair_occ2<MT_>, &raised, pl, st); }
     UNETMI_B16(1, 1, false) UNETMI_B16(1, 2, false) UNETMI_B16(2, 1, false) UNETMI_B16(2, 2, false)
     UNETMI_B16(3, 1, false) UNETMI_B16(3, 2, false) UNETMI_B16(4, 1, false)
@@ -964,6 +1039,8 @@ static int conv2d_b16_launch(const UnetmiConvDesc* d, const void* in0, const voi
     UNETMI_B16_OCC2(1, 1) UNETMI_B16_OCC2(1, 2) UNETMI_B16_OCC2(2, 1) UNETMI_B16_OCC2(2, 2)
     UNETMI_B16_OCC2(3, 1) UNETMI_B16_OCC2(3, 2) UNETMI_B16_OCC2(4, 1)
     UNETMI_B16_PAIR(1) UNETMI_B16_PAIR(2) UNETMI_B16_PAIR(3)
+    UNETMI_B16_RT2(1) UNETMI_B16_RT2(2) UNETMI_B16_RT2(3)
+#undef UNETMI_B16_RT2
 #undef UNETMI_B16_OCC2
 #undef UNETMI_B16_PAIR
 #undef UNETMI_B16
