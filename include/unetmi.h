@@ -287,6 +287,9 @@ int unetmi_glu_fwd(int N, int K, int HW, const void* z, const float* scale, cons
  *                remainder and a second MFMA adds it (fp32-weight accuracy at twice the matrix work),
  *   reserved[2]  1: write out as plain fp32 NCHW [N,K,OH,OW] instead of the blocked layout (heads). */
 size_t unetmi_conv2d_b16_packed_weight_bytes(const UnetmiConvDesc* d);
+/* HOST function, a measurement aid like unetmi_conv2d_kernel_name: the kernel instantiation unetmi_conv2d_b16_fwd
+ * (head_channels = 0) or unetmi_conv2d_b16_head_fwd launches for this descriptor, e.g. "conv_b16_kernel_rt2<3>". */
+int unetmi_conv2d_b16_kernel_name(const UnetmiConvDesc* d, int head_channels, char* buf, size_t n);
 /* HOST function; w: torch-layout fp32 weight, packed: host buffer of the size above. */
 int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void* packed);
 int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,

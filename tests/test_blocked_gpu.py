@@ -72,6 +72,30 @@ CASES = [
     c[0], c[1], c[2], c[3][0], c[3][1], c[4][0], c[4][1], "T" if c[7] else "C"))
 @pytest.mark.parametrize("halves", [1, 2])
 def test_conv_b16_matches_cpu(device, case, halves):
+    run_case(device, case, halves, 2)
+
+
+# Shapes large enough for the plan to take the two-rows-per-wave kernels (16-row workgroup tiles; every phase at
+# least 16 rows high and 512 workgroups or more): a (7,1) layer over 135 channels, whose regular plan is a
+# one-column-tile kernel, and a time-stride-2 transposed 7x5 layer with three channel tiles.
+RT2_CASES = [
+    (16, (90, 45, 90, (7, 1), (1, 1), (3, 0), (0, 0), True, 64, 512), "conv_b16_kernel_rt2<3>"),
+    (28, (90, 90, 90, (7, 5), (2, 2), (3, 2), (0, 1), True, 33, 128), "conv_b16_kernel_pair_rt2<3>"),
+]
+
+
+@pytest.mark.parametrize("N,case,kernel", RT2_CASES, ids=["7x1_135ch", "7x5_s22_T"])
+def test_conv_b16_two_rows_per_wave(device, N, case, kernel):
+    from unet_amd import _lib
+    from unet_amd.ops import b16_desc, conv_b16_kernel_name
+    C0, C1, K, k, s, p, op, transposed, H, W = case
+    geom = [K, k[0], k[1], s[0], s[1], p[0], p[1], 1, 1, op[0], op[1]]
+    d = b16_desc(N, C0, C1, H, W, geom, int(transposed), _lib.ACT_LEAKY, 0, 0, 1, 1, False)
+    assert conv_b16_kernel_name(d) == kernel, "the plan no longer takes the two-row kernel for this shape"
+    run_case(device, case, 1, N, with_head=False)
+
+
+def run_case(device, case, halves, N, with_head=True):
     from unet_amd.blocked import BlockedConv, BlockedTensor
     C0, C1, K, k, s, p, op, transposed, H, W = case
     g = torch.Generator().manual_seed(hash(case) % 1000 + halves)
@@ -89,7 +113,6 @@ def test_conv_b16_matches_cpu(device, case, halves):
         bn.bias.copy_(torch.randn(K, generator=g) * 0.1)
         bn.running_mean.copy_(torch.randn(K, generator=g) * 0.1)
         bn.running_var.copy_(torch.rand(K, generator=g) + 0.5)
-    N = 2
     x0 = torch.randn(N, C0, H, W, generator=g)
     x1 = torch.randn(N, C1, H, W, generator=g) if C1 else None
     gate = torch.rand(N, K, generator=g) + 0.25
@@ -124,6 +147,8 @@ def test_conv_b16_matches_cpu(device, case, halves):
     raw = got.data.permute(0, 1, 4, 2, 3).reshape(N, -1, *got.data.shape[2:4])
     if raw.shape[1] > K:
         assert raw[:, K:].float().abs().max().item() == 0.0
+    if not with_head:
+        return
     # the layer + a 1x1 head + squash as one launch (the layer's result never leaves the fp32 accumulators):
     # planar and pixel-interleaved output, 1..4 head channels
     from unet_amd import _lib

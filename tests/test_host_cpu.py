@@ -374,6 +374,28 @@ def test_blocked_conv_folds_only_eval_batchnorm_and_handles_affine_false():
         BlockedConv(conv, untracked, nn.ReLU())._prepare(16, 0, torch.device("cpu"))
 
 
+def test_bf16_plan_takes_two_row_kernels_where_they_pay():
+    """Host logic only (unetmi_conv2d_b16_kernel_name launches nothing).  DSUNet's benchmark shapes at batch 32: the
+    (7,1) last decoder over 135 channels and the stride-(2,2) 7x5 decoder take the two-rows-per-wave kernels, the
+    two-column-tile layers with two resident workgroups keep theirs, a layer with a fused head takes a one-column-tile
+    kernel, and a small batch never takes the two-row kernels."""
+    from unet_amd import _lib
+    from unet_amd.ops import b16_desc, conv_b16_kernel_name
+
+    def name(N, C0, C1, H, W, geom, head=0):
+        return conv_b16_kernel_name(b16_desc(N, C0, C1, H, W, geom, 1, _lib.ACT_LEAKY, 0, 0, 0, 1, False), head)
+
+    dec9, dec8 = [90, 7, 1, 1, 1, 3, 0, 1, 1, 0, 0], [90, 1, 7, 1, 1, 0, 3, 1, 1, 0, 0]
+    dec7 = [90, 7, 5, 2, 2, 3, 2, 1, 1, 0, 1]
+    assert name(32, 90, 45, 257, 512, dec9) == "conv_b16_kernel_rt2<3>"
+    assert name(32, 90, 45, 257, 512, dec9, head=2) == "conv_b16_kernel_occ2<3, 1>"
+    assert name(32, 90, 45, 257, 512, dec8) == "conv_b16_kernel_occ2<3, 2>"
+    assert name(32, 90, 90, 129, 256, dec7) == "conv_b16_kernel_pair_rt2<3>"
+    assert name(2, 90, 90, 33, 128, dec7) == "conv_b16_kernel_pair_occ2<3>"
+    with pytest.raises(_lib.UnetmiError, match="time-stride-2"):
+        name(32, 90, 90, 129, 256, dec7, head=2)
+
+
 def test_plan_picks_the_kernel_family_from_the_grid():
     """Host logic only (unetmi_conv2d_kernel_name launches nothing): which MFMA kernel family a layer gets depends on
     its grid, the packed weight image does not.  Shapes: the benchmark's 7x5 encoder, its 1x7 layer, its stride-2x2

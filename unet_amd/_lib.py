@@ -53,6 +53,7 @@ EXPORTED_SYMBOLS = (
     "unetmi_glu_fwd",
     "unetmi_instnorm_act_fwd",
     "unetmi_conv2d_b16_packed_weight_bytes",
+    "unetmi_conv2d_b16_kernel_name",
     "unetmi_conv2d_b16_pack_weights",
     "unetmi_conv2d_b16_fwd",
     "unetmi_conv2d_b16_head_fwd",
@@ -145,6 +146,8 @@ def _load():
     lib.unetmi_adam_step.argtypes = [sz] + [fp] * 4 + [cf] * 6 + [ci, vp]
     lib.unetmi_conv2d_b16_packed_weight_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.unetmi_conv2d_b16_packed_weight_bytes.restype = sz
+    lib.unetmi_conv2d_b16_kernel_name.argtypes = [ctypes.POINTER(ConvDesc), ci, ctypes.c_char_p, sz]
+    lib.unetmi_conv2d_b16_kernel_name.restype = ctypes.c_int
     lib.unetmi_conv2d_b16_pack_weights.argtypes = [ctypes.POINTER(ConvDesc), fp, fp]
     lib.unetmi_conv2d_b16_pack_weights.restype = ctypes.c_int
     lib.unetmi_conv2d_b16_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 9 + [vp]

@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
@@ -894,12 +895,16 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
         if ((rt_mode == 2 || (min_rows >= 2 * kB16Waves && wg_rt >= 512)) && ib <= (size_t)kB16MaxQ * kB16Waves * 1024) {
             for (int ar = allrows_ok ? 1 : 0; ar >= 0 && !taken; --ar) {
                 const int wbuf = (ar ? max_nth : 1) * max_ntws * pl->MT * 1024;
+                // A channel group that is ONE step needs its input two groups ahead (a step's counted wait lets the
+                // step's own loads fly on, and the next group's input would be one of them): three input images and
+                // the ring of 3, else two images, a ring of 2 and a full wait per step.
                 const bool single_step_group = (ar || one_row_phase) && hl == 1;
-                for (int din = single_step_group ? 2 : 1; din >= 1 && !taken; --din) {
-                    const size_t lds = (size_t)(din + 1) * ib + (size_t)3 * wbuf + par_bytes;
+                for (int deep = 1; deep >= 0 && !taken; --deep) {
+                    const int din = deep ? (single_step_group ? 2 : 1) : 1, wring = deep ? 3 : 2;
+                    const size_t lds = (size_t)(din + 1) * ib + (size_t)wring * wbuf + par_bytes;
                     if (lds > 160 * 1024) continue;
                     a.allrows = ar; a.w_buf_bytes = wbuf;
-                    pl->NT = 2; pl->RT = 2; pl->occ2 = false; a.din = din; a.wring = 3; a.in_buf_bytes = (int)ib;
+                    pl->NT = 2; pl->RT = 2; pl->occ2 = false; a.din = din; a.wring = wring; a.in_buf_bytes = (int)ib;
                     pl->lds_bytes = lds;
                     taken = found = true;
                 }
@@ -953,6 +958,22 @@ size_t unetmi_conv2d_b16_packed_weight_bytes(const UnetmiConvDesc* d) {
     std::string err;
     if (!make_b16_plan(*d, &pl, &err)) { api_fail(UNETMI_E_BAD_DESC, err); return 0; }
     return pl.packed_bytes;
+}
+
+int unetmi_conv2d_b16_kernel_name(const UnetmiConvDesc* d, int head_channels, char* buf, size_t n) {
+    if (!d || !buf || n == 0) return api_fail(UNETMI_E_BAD_ARG, "conv2d_b16_kernel_name: null argument");
+    B16Plan pl;
+    std::string err;
+    if (!make_b16_plan(*d, &pl, &err, head_channels)) return api_fail(UNETMI_E_BAD_DESC, err);
+    const bool gen = d->act != UNETMI_ACT_NONE && d->act != UNETMI_ACT_LEAKY && d->act != UNETMI_ACT_RELU;
+    std::string name;
+    const std::string mt = std::to_string(pl.MT), nt = std::to_string(pl.NT);
+    if (pl.RT == 2) name = std::string(pl.args.pair ? "conv_b16_kernel_pair_rt2<" : "conv_b16_kernel_rt2<") + mt + ">";
+    else if (pl.args.pair) name = std::string(pl.occ2 ? "conv_b16_kernel_pair_occ2<" : "conv_b16_kernel_pair<") + mt + ">";
+    else if (pl.occ2) name = "conv_b16_kernel_occ2<" + mt + ", " + nt + ">";
+    else name = "conv_b16_kernel<" + mt + ", " + nt + ", " + (gen ? "true" : "false") + ">";
+    std::snprintf(buf, n, "%s", name.c_str());
+    return UNETMI_OK;
 }
 
 int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void* packed) {

@@ -80,6 +80,14 @@ def conv_kernel_name(desc):
     return buf.value.decode()
 
 
+def conv_b16_kernel_name(desc, head_channels=0):
+    """The kernel instantiation the bf16-operand entry points launch for ``desc`` (unetmi_conv2d_b16_kernel_name)."""
+    buf = ctypes.create_string_buffer(128)
+    check(_lib.lib.unetmi_conv2d_b16_kernel_name(ctypes.byref(desc), int(head_channels), buf, len(buf)),
+          "unetmi_conv2d_b16_kernel_name")
+    return buf.value.decode()
+
+
 # Optional per-launch observer (bench.py's roofline leg): called as
 # fn(op_name, desc, start_event, end_event) with torch.cuda events recorded on
 # the launch stream immediately around the kernel.
