@@ -295,6 +295,14 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
 int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
                           const float* bias, const float* scale, const float* shift, const float* act_param,
                           const float* gate, void* out, void* stream);
+/* unetmi_conv2d_b16_fwd writing plain fp32 NCHW [N,K,OH,OW] (the descriptor's reserved[2] is taken as 1) with an
+ * optional fp32 NCHW tensor of that shape added to the result -- the `y + res` in front of the next block of an
+ * additive-skip decoder (ResUNet.py:206-210).  Together with unetmi_blocked_from_nchw_sum it lets a network whose
+ * tensors stay fp32 NCHW run single convolutions with bfloat16 operands (ResUNet's strided Encoder / Decoder
+ * blocks on a bfloat16 input, ResUNet.py:59-113). */
+int unetmi_conv2d_b16_nchw_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
+                               const float* bias, const float* scale, const float* shift, const float* act_param,
+                               const float* gate, const float* residual, float* out, void* stream);
 /* The last decoder of such a chain together with the network's 1x1 mask head and its squash
  * (DSUNet.py:616-628 with CRM.forward :355-359: decoder -> Conv2d(C, 2, 1) -> tanh / sigmoid / softplus): the
  * decoder's result stays in the fp32 accumulators (it is never rounded or written), and per pixel
@@ -310,6 +318,10 @@ int unetmi_conv2d_b16_head_fwd(const UnetmiConvDesc* d, const void* in0, const v
 /* Layout conversion either side of such a chain: src NCHW [N,C,HW] (UNETMI_DTYPE_*) -> blocked, and back.
  * These have no counterpart in the reference (its tensors are NCHW throughout). */
 int unetmi_blocked_from_nchw(int N, int C, int HW, const void* src, int src_dtype, void* dst, void* stream);
+/* The same with a second tensor of the same shape and storage type added first (src + src2 in fp32, rounded once;
+ * src2 may be null): the summed skip in front of a decoder (ResUNet.py:209) costs no pass of its own. */
+int unetmi_blocked_from_nchw_sum(int N, int C, int HW, const void* src, const void* src2, int src_dtype, void* dst,
+                                 void* stream);
 int unetmi_nchw_from_blocked(int N, int C, int HW, const void* src, void* dst, int dst_dtype, void* stream);
 
 

@@ -143,6 +143,14 @@ def run_case(device, case, halves, N, with_head=True):
     got_f32 = head(b0, b1, gate.to(device)).cpu()
     e = rel_err(got_f32, want)
     assert e <= 1e-4, "fp32-output blocked conv: rel-err {:.3e}".format(e)
+    # ... plus an added fp32 tensor, and with the input formed as a sum during the layout conversion
+    res = torch.randn(want.shape, generator=g)
+    got_res = head(b0, b1, gate.to(device), residual=res.to(device)).cpu()
+    e = rel_err(got_res, want + res)
+    assert e <= 1e-4, "fp32-output blocked conv + residual: rel-err {:.3e}".format(e)
+    xa, xb_ = x0 * 0.25, x0 - x0 * 0.25
+    summed = BlockedTensor.from_nchw(xa.to(device), addend=xb_.to(device))
+    assert torch.equal(summed.data.cpu(), BlockedTensor.from_nchw((xa + xb_).to(device)).data.cpu())
     # padded output channels are exact zeros (the next layer multiplies them by zero weights)
     raw = got.data.permute(0, 1, 4, 2, 3).reshape(N, -1, *got.data.shape[2:4])
     if raw.shape[1] > K:

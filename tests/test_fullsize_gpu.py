@@ -194,7 +194,13 @@ def test_resunet_bf16_full_length(device):
         got = dev(x.to(device))
         assert got.dtype == torch.bfloat16 and tuple(got.shape) == (2, 2, 257, 501)
         l2, mx = bf16_figures(got, want)
-        print("ResUNet bf16 T=501 (default path): relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+        print("ResUNet bf16 T=501 (default path: fp32 tensors, bf16 operands in the strided convolutions): "
+              "relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+        assert l2 <= BF16_TOL and mx <= BF16_TOL
+        dev.bf16_operands = 0
+        l2, mx = bf16_figures(dev(x.to(device)), want)
+        dev.bf16_operands = 1
+        print("ResUNet bf16 T=501 (fp32 products, bfloat16 at the boundary only): relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
         assert l2 <= BF16_TOL and mx <= BF16_TOL
         dev.bf16_storage = True
         got = dev(x.to(device))

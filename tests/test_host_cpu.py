@@ -335,6 +335,9 @@ def test_every_entry_point_is_a_dispatcher_op_with_shape_inference():
         assert ops.conv2d_b16_fwd(b, 8, None, 0, w, c, c, c, None, None, geom, [0, 0, 0, 1, 0]).shape == (2, 2, 5, 7, 8)
         out = ops.conv2d_b16_fwd(b, 8, None, 0, w, c, c, c, None, None, geom, [0, 0, 0, 1, 1])
         assert out.shape == (2, 4, 5, 7) and out.dtype == torch.float32
+        assert ops.blocked_from_nchw_sum(z, z).shape == (2, 2, 5, 7, 8)
+        out = ops.conv2d_b16_nchw_fwd(b, 8, None, 0, w, c, c, c, None, None, torch.empty(2, 4, 5, 7), geom, [0, 0, 0, 1])
+        assert out.shape == (2, 4, 5, 7) and out.dtype == torch.float32
         hw = torch.empty(2, 4)
         out = ops.conv2d_b16_head_fwd(b, 8, None, 0, w, c, c, c, None, None, hw, None, geom, [0, 0, 0, 1, 6, 1])
         assert out.shape == (2, 5, 7, 2) and out.dtype == torch.float32           # interleaved: a complex64 [2,5,7]

@@ -534,9 +534,19 @@ def test_resunet_bf16_storage(device):
     xb = x.to(torch.bfloat16)
     with torch.no_grad():
         want = ref(xb.float())                      # same (bf16-representable) input values
-        got = dev(xb.to(device))                    # default: bfloat16 at the boundary, fp32 tensors inside
-        assert got.dtype == torch.bfloat16
-        assert_bf16_close(got, want, "ResUNet bf16 in/out, fp32 inside", max_tol=BF16_DEFAULT_PATH_TOL)
+        # default: every tensor fp32 inside, the strided convolutions with bfloat16 operands (one weight half);
+        # 2: weights as two halves; 0: fp32 products everywhere (bfloat16 at the boundary only)
+        assert dev.bf16_operands == 1
+        for operands in (1, 2, 0):
+            dev.bf16_operands = operands
+            got = dev(xb.to(device))
+            assert got.dtype == torch.bfloat16
+            assert_bf16_close(got, want, "ResUNet bf16 in/out, fp32 tensors inside, bf16_operands={}".format(operands),
+                              max_tol=BF16_DEFAULT_PATH_TOL)
+        blocked = [m for m in dev.modules() if getattr(m, "_blocked", None) and any(m._blocked.values())]
+        assert len(blocked) >= 10, "the strided convolutions did not take the bf16-operand kernels"
+        assert all(m.bf16_operands == 0 for m in dev.modules() if hasattr(m, "bf16_operands") and m is not dev)
+        dev.bf16_operands = 1
         dev.bf16_storage = True                     # every intermediate tensor bfloat16
         got = dev(xb.to(device))
     assert got.dtype == torch.bfloat16

@@ -158,13 +158,26 @@ class ResUNet(nn.Module):
     # error 1.0e-2 .. 1.4e-2 against 2e-3).  True: bfloat16 storage of every intermediate tensor (half the
     # activation memory), fp32 arithmetic.
     bf16_storage = False
+    # What else a bfloat16 input selects (default path, bf16_storage False): 1 or 2 = the strided Encoder / Decoder
+    # convolutions (3x3 stride (2,1), (4,1) / (3,1) transposed: a third of the fp32 forward's time) run with
+    # bfloat16 OPERANDS on the matrix cores -- 2: weights as bfloat16 plus their rounding remainder -- while every
+    # tensor stays fp32 NCHW and the ResBlocks, the LSTM and the 1x1 paths keep fp32 products; 0 = fp32 products
+    # everywhere (bfloat16 at the boundary only).
+    bf16_operands = 1
 
     def forward(self, input):
         require_device_tensor(input, "ResUNet")
         if self.training:
             return self._forward_train(input)
         if input.dtype == torch.bfloat16 and not self.bf16_storage:
-            return self.forward(input.float()).to(torch.bfloat16)
+            blocks = [m for m in self.modules() if isinstance(m, (Encoder, Decoder))] if self.bf16_operands else []
+            for m in blocks:
+                m.bf16_operands = int(self.bf16_operands)
+            try:
+                return self.forward(input.float()).to(torch.bfloat16)
+            finally:
+                for m in blocks:
+                    m.bf16_operands = 0
         B, _, F, T = input.shape
         x = torch.empty((B, 64, F, T), dtype=input.dtype, device=input.device)
         self._input_branch(self.layer_data, "_in_data", input[:, :-2].contiguous(), x, 0)

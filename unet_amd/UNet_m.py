@@ -49,9 +49,47 @@ class _FusedBlock(nn.Module):
     BatchNorm2d and the activation is one the epilogue implements; otherwise
     the HIP convolution followed by torch's norm/activation on the device."""
 
+    # 0: fp32 products (exact-fp32 MFMA).  1 / 2: the network this block belongs to asked for bfloat16 OPERANDS on
+    # tensors that stay fp32 NCHW (ResUNet on a bfloat16 input): the input is converted to the channel-blocked bfloat16
+    # layout on the way in (a summed skip is added in that pass), the convolution runs on the bf16 matrix instruction
+    # (16x the fp32 rate) with fp32 accumulation and writes fp32 NCHW, an added tensor included; 2 = weights as
+    # bfloat16 plus their rounding remainder.  Blocks the bf16 kernel does not serve keep the fp32 path.
+    bf16_operands = 0
+
     def _setup(self, conv_attr):
         self._conv_attr = conv_attr
         self._fused = None
+        self._blocked = {}
+
+    def _run_bf16_operands(self, x, skip, in_mode, residual, halves):
+        """The block through unet_amd.blocked on fp32 NCHW tensors, or None when it is not one that path serves."""
+        from .blocked import BlockedConv, BlockedTensor
+        from .fused import activation_code
+        conv = getattr(self, self._conv_attr)
+        layer = self._blocked.get(halves)
+        if layer is None:
+            code = activation_code(self.acti)
+            ok = (conv.out_channels <= 128 and _pair(conv.kernel_size) != (1, 1) and conv.groups == 1
+                  and getattr(conv, "padding_mode", "zeros") == "zeros" and not isinstance(conv.padding, str)
+                  and isinstance(self.bn, (nn.BatchNorm2d, nn.Identity))
+                  and (isinstance(self.bn, nn.Identity) or self.bn.running_mean is not None)
+                  and code is not None and code[0] in (_lib.ACT_NONE, _lib.ACT_LEAKY, _lib.ACT_RELU))
+            layer = BlockedConv(conv, self.bn, self.acti, halves=halves, nchw_out=True) if ok else False
+            self._blocked[halves] = layer
+        if layer is False:
+            return None
+        try:
+            if skip is not None and in_mode == _lib.IN_ADD:
+                xb, sb = BlockedTensor.from_nchw(x.contiguous(), addend=skip.contiguous()), None
+            else:
+                xb = BlockedTensor.from_nchw(x.contiguous())
+                sb = None if skip is None else BlockedTensor.from_nchw(skip.contiguous())
+            return layer(xb, sb, None, residual=None if residual is None else residual.contiguous())
+        except _lib.UnetmiError as e:
+            if e.code not in (_lib.E_UNSUPPORTED, _lib.E_BAD_DESC):
+                raise
+            self._blocked[halves] = False           # e.g. LDS images of this geometry exceed a CU: fp32 path from now on
+            return None
 
     def _layer(self):
         if self._fused is None:
@@ -63,6 +101,10 @@ class _FusedBlock(nn.Module):
         require_device_tensor(x, type(self).__name__)
         if self.training:
             return self._run_differentiable(x, skip, in_mode, gate, residual)
+        if self.bf16_operands and x.dtype == torch.float32 and gate is None:
+            y = self._run_bf16_operands(x, skip, in_mode, residual, int(self.bf16_operands))
+            if y is not None:
+                return y
         layer = self._layer()
         if layer.fusable():
             return layer(x, skip, in_mode=in_mode, gate=gate, residual=residual)

@@ -57,6 +57,8 @@ EXPORTED_SYMBOLS = (
     "unetmi_conv2d_b16_pack_weights",
     "unetmi_conv2d_b16_fwd",
     "unetmi_conv2d_b16_head_fwd",
+    "unetmi_conv2d_b16_nchw_fwd",
+    "unetmi_blocked_from_nchw_sum",
     "unetmi_blocked_from_nchw",
     "unetmi_nchw_from_blocked",
     "unetmi_bn_running_update",
@@ -152,6 +154,10 @@ def _load():
     lib.unetmi_conv2d_b16_pack_weights.restype = ctypes.c_int
     lib.unetmi_conv2d_b16_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 9 + [vp]
     lib.unetmi_conv2d_b16_fwd.restype = ctypes.c_int
+    lib.unetmi_conv2d_b16_nchw_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 10 + [vp]
+    lib.unetmi_conv2d_b16_nchw_fwd.restype = ctypes.c_int
+    lib.unetmi_blocked_from_nchw_sum.argtypes = [ci] * 3 + [fp, fp, ci, fp, vp]
+    lib.unetmi_blocked_from_nchw_sum.restype = ctypes.c_int
     lib.unetmi_conv2d_b16_head_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 10 + [ci] * 3 + [fp, vp]
     lib.unetmi_conv2d_b16_head_fwd.restype = ctypes.c_int
     lib.unetmi_blocked_from_nchw.argtypes = [ci] * 3 + [fp, ci, fp, vp]

@@ -33,9 +33,12 @@ class BlockedTensor:
         return (N, self.C, H, W)
 
     @staticmethod
-    def from_nchw(x):
-        """x: contiguous fp32 or bfloat16 device tensor [N,C,H,W]."""
-        return BlockedTensor(_ops.blocked_from_nchw(x), x.shape[1])
+    def from_nchw(x, addend=None):
+        """x: contiguous fp32 or bfloat16 device tensor [N,C,H,W]; ``addend`` (same shape and type) is added first
+        (in fp32, one rounding)."""
+        if addend is None:
+            return BlockedTensor(_ops.blocked_from_nchw(x), x.shape[1])
+        return BlockedTensor(_ops.blocked_from_nchw_sum(x, addend), x.shape[1])
 
     def to_nchw(self, dtype=torch.bfloat16):
         if dtype not in (torch.bfloat16, torch.float32):
@@ -138,8 +141,15 @@ class BlockedConv:
         self._img[(C0, C1)] = st
         return st
 
-    def __call__(self, x, skip=None, gate=None):
+    def __call__(self, x, skip=None, gate=None, residual=None):
+        """``residual`` (fp32 NCHW, shaped like the output; with ``nchw_out`` only) is added to the result."""
         st = self._prepare(x.C, 0 if skip is None else skip.C, x.data.device)
+        if residual is not None:
+            if not self.nchw_out:
+                raise ValueError("BlockedConv: a residual goes with the fp32 NCHW output")
+            return _ops.conv2d_b16_nchw_fwd(x.data, x.C, None if skip is None else skip.data, 0 if skip is None else skip.C,
+                                            st["w"], st["bias"], st["scale"], st["shift"], st["ap"], gate, residual,
+                                            list(self.geom), [int(self.transposed), int(self.act_code), 0, int(self.halves)])
         return conv2d_b16(x, skip, st["w"], st["bias"], st["scale"], st["shift"], st["ap"], gate, self.geom,
                           self.transposed, self.act_code, 0, self.halves, self.nchw_out)
 

@@ -85,6 +85,7 @@ struct B16Args {
     int act, act_first, act_pc, out_nchw_f32;
     // fused 1x1 head: out = head_act(head_w [P][K] . layer_output + head_b) per pixel, written as fp32 instead of the
     // layer's own output (head_P = 0: no head).  head_il: [N][OH][OW][P] instead of [N][P][OH][OW].
+    const float* residual;   // out_nchw_f32 only: fp32 [N,K,OH,OW] added to the result, or null
     const float* head_w; const float* head_b;
     int head_P, head_act, head_il;
     B16Phase ph[kB16MaxPhase];
@@ -239,8 +240,10 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (ok[nt] && m0 + r < p.K)
-                            static_cast<float*>(p.out)[((size_t)n * p.K + m0 + r) * OHW + pix[nt]] = v[nt][r];
+                        if (ok[nt] && m0 + r < p.K) {
+                            const size_t o = ((size_t)n * p.K + m0 + r) * OHW + pix[nt];
+                            static_cast<float*>(p.out)[o] = p.residual ? v[nt][r] + p.residual[o] : v[nt][r];
+                        }
             } else if constexpr (NT == 2) {
                 // lanes l and l+32 hold the two halves of a pixel's record in each column tile: swapping the upper
                 // lanes of tile 0 with the lower lanes of tile 1 leaves every lane with one whole 16-byte record
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(512, 2) void conv_b16_kernel_pair_rt2(const B16Args
 // ---- layout conversion ------------------------------------------------------------------------
 // NCHW (fp32 or bfloat16) -> blocked; a thread owns one pixel of one 8-channel block.
 template <bool SRC_BF16>
-__global__ __launch_bounds__(256) void to_blocked_kernel(const void* src, char* dst, int C, int CB, int HW) {
+__global__ __launch_bounds__(256) void to_blocked_kernel(const void* src, const void* src2, char* dst, int C, int CB, int HW) {
     const int pix = blockIdx.x * 256 + threadIdx.x;
     const int blk = blockIdx.y, n = blockIdx.z;
     if (pix >= HW) return;
@@ -694,7 +697,12 @@ __global__ __launch_bounds__(256) void to_blocked_kernel(const void* src, char* 
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int c = blk * 8 + k;
-        v[k] = c < C ? f32_to_bf16_bits(ld_act<SRC_BF16>(src, ((size_t)n * C + c) * HW + pix)) : (unsigned short)0;
+        float f = 0.f;
+        if (c < C) {
+            f = ld_act<SRC_BF16>(src, ((size_t)n * C + c) * HW + pix);
+            if (src2) f += ld_act<SRC_BF16>(src2, ((size_t)n * C + c) * HW + pix);       // summed in fp32, rounded once
+        }
+        v[k] = f32_to_bf16_bits(f);
     }
     uint4 o;
     o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
@@ -1018,7 +1026,7 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
 static int conv2d_b16_launch(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
                              const float* bias, const float* scale, const float* shift, const float* act_param,
                              const float* gate, const float* head_w, const float* head_b, int head_P, int head_act,
-                             int head_il, void* out, void* stream) {
+                             int head_il, void* out, void* stream, const float* residual = nullptr) {
     if (!d) return api_fail(UNETMI_E_BAD_ARG, "null descriptor");
     B16Plan pl;
     std::string err;
@@ -1032,6 +1040,8 @@ static int conv2d_b16_launch(const UnetmiConvDesc* d, const void* in0, const voi
     a.in0 = static_cast<const char*>(in0); a.in1 = static_cast<const char*>(in1); a.w = static_cast<const char*>(wpacked);
     a.bias = bias; a.scale = scale; a.shift = shift; a.act_param = act_param; a.gate = gate; a.out = out;
     a.head_w = head_w; a.head_b = head_b; a.head_P = head_P; a.head_act = head_act; a.head_il = head_il;
+    a.residual = residual;
+    if (residual && !a.out_nchw_f32) return api_fail(UNETMI_E_BAD_DESC, "conv2d_b16: a residual goes with the fp32 NCHW output only");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipErrorInvalidConfiguration;
     const bool gen = d->act != UNETMI_ACT_NONE && d->act != UNETMI_ACT_LEAKY && d->act != UNETMI_ACT_RELU;
@@ -1076,6 +1086,16 @@ int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* 
                              UNETMI_ACT_NONE, 0, out, stream);
 }
 
+int unetmi_conv2d_b16_nchw_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
+                               const float* bias, const float* scale, const float* shift, const float* act_param,
+                               const float* gate, const float* residual, float* out, void* stream) {
+    if (!d) return api_fail(UNETMI_E_BAD_ARG, "null descriptor");
+    UnetmiConvDesc dd = *d;
+    dd.reserved[2] = 1;                         // fp32 NCHW output
+    return conv2d_b16_launch(&dd, in0, in1, wpacked, bias, scale, shift, act_param, gate, nullptr, nullptr, 0,
+                             UNETMI_ACT_NONE, 0, out, stream, residual);
+}
+
 int unetmi_conv2d_b16_head_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
                                const float* bias, const float* scale, const float* shift, const float* act_param,
                                const float* gate, const float* head_w, const float* head_b, int head_channels,
@@ -1092,6 +1112,11 @@ int unetmi_conv2d_b16_head_fwd(const UnetmiConvDesc* d, const void* in0, const v
 }
 
 int unetmi_blocked_from_nchw(int N, int C, int HW, const void* src, int src_dtype, void* dst, void* stream) {
+    return unetmi_blocked_from_nchw_sum(N, C, HW, src, nullptr, src_dtype, dst, stream);
+}
+
+int unetmi_blocked_from_nchw_sum(int N, int C, int HW, const void* src, const void* src2, int src_dtype, void* dst,
+                                 void* stream) {
     if (N < 0 || C < 1 || HW < 1) return api_fail(UNETMI_E_BAD_DESC, "blocked_from_nchw: bad sizes");
     if (N == 0) return UNETMI_OK;
     if (!src || !dst) return api_fail(UNETMI_E_BAD_ARG, "blocked_from_nchw: null pointer");
@@ -1099,8 +1124,8 @@ int unetmi_blocked_from_nchw(int N, int C, int HW, const void* src, int src_dtyp
     if (N > 65535 || CB > 65535) return api_fail(UNETMI_E_UNSUPPORTED, "blocked_from_nchw: N or C too large");
     const dim3 grid((HW + 255) / 256, CB, N);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (src_dtype == UNETMI_DTYPE_BF16) hipLaunchKernelGGL((to_blocked_kernel<true>), grid, dim3(256), 0, st, src, static_cast<char*>(dst), C, CB, HW);
-    else if (src_dtype == UNETMI_DTYPE_F32) hipLaunchKernelGGL((to_blocked_kernel<false>), grid, dim3(256), 0, st, src, static_cast<char*>(dst), C, CB, HW);
+    if (src_dtype == UNETMI_DTYPE_BF16) hipLaunchKernelGGL((to_blocked_kernel<true>), grid, dim3(256), 0, st, src, src2, static_cast<char*>(dst), C, CB, HW);
+    else if (src_dtype == UNETMI_DTYPE_F32) hipLaunchKernelGGL((to_blocked_kernel<false>), grid, dim3(256), 0, st, src, src2, static_cast<char*>(dst), C, CB, HW);
     else return api_fail(UNETMI_E_BAD_DESC, "blocked_from_nchw: unknown dtype");
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("blocked_from_nchw launch: ") + hipGetErrorString(e));

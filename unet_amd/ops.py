@@ -416,10 +416,14 @@ _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
 _LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
 _LIBRARY.define("conv2d_b16_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
                 "Tensor shift, Tensor? act_param, Tensor? gate, int[] geom, int[] flags) -> Tensor")
+_LIBRARY.define("blocked_from_nchw_sum(Tensor x, Tensor? x2) -> Tensor")
+_LIBRARY.define("conv2d_b16_nchw_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
+                "Tensor shift, Tensor? act_param, Tensor? gate, Tensor? residual, int[] geom, int[] flags) -> Tensor")
 _LIBRARY.define("conv2d_b16_head_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
                 "Tensor shift, Tensor? act_param, Tensor? gate, Tensor head_w, Tensor? head_b, int[] geom, int[] flags) -> Tensor")
 # conv2d_wgrad flags = [transposed, in_mode]; conv2d_b16_fwd flags = [transposed, act, act_first, halves, nchw_out];
-# conv2d_b16_head_fwd flags = [transposed, act, act_first, halves, head_act, interleaved]
+# conv2d_b16_head_fwd flags = [transposed, act, act_first, halves, head_act, interleaved];
+# conv2d_b16_nchw_fwd flags = [transposed, act, act_first, halves]
 
 _ws_cache = {}
 
@@ -652,15 +656,21 @@ def blocks_for(C):
     return 2 * ((C + 15) // 16)
 
 
-def _blocked_from_nchw_cuda(x):
+def _blocked_from_nchw_sum_cuda(x, x2):
     if not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
         raise ValueError("unetmi::blocked_from_nchw: contiguous 4-D device tensor expected")
+    if x2 is not None and (x2.shape != x.shape or x2.dtype != x.dtype or x2.device != x.device or not x2.is_contiguous()):
+        raise ValueError("unetmi::blocked_from_nchw_sum: x2 must match x in shape, dtype and device and be contiguous")
     N, C, H, W = x.shape
     out = torch.empty((N, blocks_for(C), H, W, 8), dtype=torch.bfloat16, device=x.device)
     with torch.cuda.device(x.device):
-        check(_lib.lib.unetmi_blocked_from_nchw(N, C, H * W, _ptr(x), dtype_code(x), _ptr(out), _stream(x)),
-              "unetmi_blocked_from_nchw")
+        check(_lib.lib.unetmi_blocked_from_nchw_sum(N, C, H * W, _ptr(x), _ptr(x2), dtype_code(x), _ptr(out), _stream(x)),
+              "unetmi_blocked_from_nchw_sum")
     return out
+
+
+def _blocked_from_nchw_cuda(x):
+    return _blocked_from_nchw_sum_cuda(x, None)
 
 
 def _nchw_from_blocked_cuda(data, C, f32):
@@ -685,7 +695,7 @@ def b16_desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, has_gate
 
 
 def _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, transposed, act, act_first,
-                    halves, nchw_out, head):
+                    halves, nchw_out, head, residual=None):
     """Checks shared by the two bf16-operand entry points, then the launch.  head: None, or (head_w [P,K], head_b
     [P] | None, head_act, interleaved) for the decoder + 1x1 head launch."""
     what = "conv2d_b16_fwd" if head is None else "conv2d_b16_head_fwd"
@@ -731,6 +741,10 @@ def _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gat
         out = torch.empty((N, d.OH, d.OW, P) if interleaved else (N, P, d.OH, d.OW), dtype=torch.float32, device=x.device)
     elif nchw_out:
         out = torch.empty((N, K, d.OH, d.OW), dtype=torch.float32, device=x.device)
+        if residual is not None:
+            _dev(residual, "residual", what)
+            if tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous():
+                raise ValueError("unetmi::{}: residual must be a contiguous fp32 [N,K,OH,OW] tensor".format(what))
     else:
         out = torch.empty((N, blocks_for(K), d.OH, d.OW, 8), dtype=torch.bfloat16, device=x.device)
     with torch.cuda.device(x.device):
@@ -738,7 +752,11 @@ def _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gat
         if obs is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if head is None:
+        if head is None and residual is not None:
+            check(_lib.lib.unetmi_conv2d_b16_nchw_fwd(ctypes.byref(d), _ptr(x), _ptr(skip), _ptr(wpacked), _ptr(bias),
+                                                      _ptr(scale), _ptr(shift), _ptr(act_param), _ptr(gate),
+                                                      _ptr(residual), _ptr(out), _stream(x)), "unetmi_conv2d_b16_nchw_fwd")
+        elif head is None:
             check(_lib.lib.unetmi_conv2d_b16_fwd(ctypes.byref(d), _ptr(x), _ptr(skip), _ptr(wpacked), _ptr(bias),
                                                  _ptr(scale), _ptr(shift), _ptr(act_param), _ptr(gate), _ptr(out),
                                                  _stream(x)), "unetmi_conv2d_b16_fwd")
@@ -759,6 +777,12 @@ def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param
                            halves, nchw_out, None)
 
 
+def _conv2d_b16_nchw_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, residual, geom, flags):
+    transposed, act, act_first, halves = flags
+    return _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, transposed, act, act_first,
+                           halves, 1, None, residual)
+
+
 def _conv2d_b16_head_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, head_w, head_b, geom, flags):
     transposed, act, act_first, halves, head_act, interleaved = flags
     return _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, transposed, act, act_first,
@@ -770,7 +794,8 @@ for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_batch_stats", 
                    ("bn_act_bwd", _bn_act_bwd_cuda), ("conv2d_wgrad", _conv2d_wgrad_cuda),
                    ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda), ("gru_recurrence", _gru_recurrence_cuda), ("dwconv2d_wgrad", _dwconv2d_wgrad_cuda),
                    ("blocked_from_nchw", _blocked_from_nchw_cuda), ("nchw_from_blocked", _nchw_from_blocked_cuda),
-                   ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda), ("conv2d_b16_head_fwd", _conv2d_b16_head_fwd_cuda)):
+                   ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda), ("conv2d_b16_head_fwd", _conv2d_b16_head_fwd_cuda),
+                   ("conv2d_b16_nchw_fwd", _conv2d_b16_nchw_fwd_cuda), ("blocked_from_nchw_sum", _blocked_from_nchw_sum_cuda)):
     _LIBRARY.impl(_name, _fn, "CUDA")
 
 
@@ -853,6 +878,20 @@ def _(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, flags
     return x.new_empty((N, blocks_for(K), OH, OW, 8))
 
 
+@torch.library.register_fake("unetmi::blocked_from_nchw_sum")
+def _(x, x2):
+    N, C, H, W = x.shape
+    return x.new_empty((N, blocks_for(C), H, W, 8), dtype=torch.bfloat16)
+
+
+@torch.library.register_fake("unetmi::conv2d_b16_nchw_fwd")
+def _(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, residual, geom, flags):
+    K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
+    N, _, H, W, _ = x.shape
+    OH, OW = conv_out_size(H, kh, sh, ph, dh, oph, flags[0]), conv_out_size(W, kw, sw, pw, dw, opw, flags[0])
+    return x.new_empty((N, K, OH, OW), dtype=torch.float32)
+
+
 @torch.library.register_fake("unetmi::conv2d_b16_head_fwd")
 def _(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, head_w, head_b, geom, flags):
     K, kh, kw, sh, sw, ph, pw, dh, dw, oph, opw = geom
@@ -877,3 +916,5 @@ blocked_from_nchw = torch.ops.unetmi.blocked_from_nchw
 nchw_from_blocked = torch.ops.unetmi.nchw_from_blocked
 conv2d_b16_fwd = torch.ops.unetmi.conv2d_b16_fwd
 conv2d_b16_head_fwd = torch.ops.unetmi.conv2d_b16_head_fwd
+conv2d_b16_nchw_fwd = torch.ops.unetmi.conv2d_b16_nchw_fwd
+blocked_from_nchw_sum = torch.ops.unetmi.blocked_from_nchw_sum
