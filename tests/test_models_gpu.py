@@ -543,7 +543,7 @@ def test_resunet_bf16_storage(device):
             assert got.dtype == torch.bfloat16
             assert_bf16_close(got, want, "ResUNet bf16 in/out, fp32 tensors inside, bf16_operands={}".format(operands),
                               max_tol=BF16_DEFAULT_PATH_TOL)
-        blocked = [m for m in dev.modules() if getattr(m, "_blocked", None) and any(m._blocked.values())]
+        blocked = [m for m in dev.modules() if getattr(m, "_blocked", None) and any(v[1] for v in m._blocked.values())]
         assert len(blocked) >= 10, "the strided convolutions did not take the bf16-operand kernels"
         assert all(m.bf16_operands == 0 for m in dev.modules() if hasattr(m, "bf16_operands") and m is not dev)
         dev.bf16_operands = 1

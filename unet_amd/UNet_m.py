@@ -61,22 +61,68 @@ class _FusedBlock(nn.Module):
         self._fused = None
         self._blocked = {}
 
-    def _run_bf16_operands(self, x, skip, in_mode, residual, halves):
-        """The block through unet_amd.blocked on fp32 NCHW tensors, or None when it is not one that path serves."""
-        from .blocked import BlockedConv, BlockedTensor
+    def _blocked_layers(self, halves):
+        """BlockedConv objects covering this block's output channels in runs of at most 128 (the bf16 kernel's limit;
+        a wider layer is several launches on one converted input, over copies of its parameter slices that are rebuilt
+        when a parameter changes), or False when the block is not one that path serves."""
+        from .blocked import BlockedConv
         from .fused import activation_code
         conv = getattr(self, self._conv_attr)
-        layer = self._blocked.get(halves)
-        if layer is None:
-            code = activation_code(self.acti)
-            ok = (conv.out_channels <= 128 and _pair(conv.kernel_size) != (1, 1) and conv.groups == 1
-                  and getattr(conv, "padding_mode", "zeros") == "zeros" and not isinstance(conv.padding, str)
-                  and isinstance(self.bn, (nn.BatchNorm2d, nn.Identity))
-                  and (isinstance(self.bn, nn.Identity) or self.bn.running_mean is not None)
-                  and code is not None and code[0] in (_lib.ACT_NONE, _lib.ACT_LEAKY, _lib.ACT_RELU))
-            layer = BlockedConv(conv, self.bn, self.acti, halves=halves, nchw_out=True) if ok else False
-            self._blocked[halves] = layer
-        if layer is False:
+        code = activation_code(self.acti)
+        K = conv.out_channels
+        pointwise = _pair(conv.kernel_size) == (1, 1)
+        ok = (conv.groups == 1 and getattr(conv, "padding_mode", "zeros") == "zeros" and not isinstance(conv.padding, str)
+              and not (pointwise and conv.in_channels < 128)          # narrow 1x1 layers are bandwidth-bound: fp32 kernel
+              and isinstance(self.bn, (nn.BatchNorm2d, nn.Identity))
+              and (isinstance(self.bn, nn.Identity) or self.bn.running_mean is not None)
+              and code is not None and code[0] in (_lib.ACT_NONE, _lib.ACT_LEAKY, _lib.ACT_RELU)
+              and (K <= 128 or not isinstance(code[1], torch.Tensor) or code[1].numel() == 1))
+        if not ok:
+            return False
+        if K <= 128:
+            return [(0, K, BlockedConv(conv, self.bn, self.acti, halves=halves, nchw_out=True))]
+        transposed = isinstance(conv, nn.ConvTranspose2d)
+        parts = []
+        with torch.no_grad():
+            for lo in range(0, K, 128):
+                hi = min(K, lo + 128)
+                kw = dict(kernel_size=conv.kernel_size, stride=conv.stride, padding=conv.padding, dilation=conv.dilation,
+                          bias=conv.bias is not None)
+                if transposed:
+                    sub = nn.ConvTranspose2d(conv.in_channels, hi - lo, output_padding=conv.output_padding, **kw)
+                    sub.weight.copy_(conv.weight[:, lo:hi])
+                else:
+                    sub = nn.Conv2d(conv.in_channels, hi - lo, **kw)
+                    sub.weight.copy_(conv.weight[lo:hi])
+                if conv.bias is not None:
+                    sub.bias.copy_(conv.bias[lo:hi])
+                norm = self.bn
+                if isinstance(norm, nn.BatchNorm2d):
+                    norm = nn.BatchNorm2d(hi - lo, eps=self.bn.eps, affine=self.bn.affine).eval()
+                    norm.running_mean.copy_(self.bn.running_mean[lo:hi])
+                    norm.running_var.copy_(self.bn.running_var[lo:hi])
+                    if self.bn.affine:
+                        norm.weight.copy_(self.bn.weight[lo:hi])
+                        norm.bias.copy_(self.bn.bias[lo:hi])
+                sub, norm = sub.to(conv.weight.device), norm.to(conv.weight.device)
+                parts.append((lo, hi, BlockedConv(sub, norm, self.acti, halves=halves, nchw_out=True)))
+        return parts
+
+    def _run_bf16_operands(self, x, skip, in_mode, residual, halves):
+        """The block through unet_amd.blocked on fp32 NCHW tensors, or None when it is not one that path serves."""
+        from .blocked import BlockedTensor
+        conv = getattr(self, self._conv_attr)
+        srcs = [conv.weight, conv.bias] + ([self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+                                           if isinstance(self.bn, nn.BatchNorm2d) else [])
+        key = (halves, isinstance(self.bn, nn.BatchNorm2d) and self.bn.training) + tuple(
+            None if t is None else (t.data_ptr(), t._version) for t in srcs)
+        hit = self._blocked.get(halves)
+        if hit is None or (hit[0] != key and hit[1] is not False and len(hit[1]) > 1) or (hit[0] != key and hit[1] is False):
+            # single-launch layers track parameter changes themselves (BlockedConv._versions); sliced copies and a
+            # refusal are redone when a parameter (or the norm's mode) changes
+            hit = self._blocked[halves] = (key, self._blocked_layers(halves))
+        parts = hit[1]
+        if parts is False:
             return None
         try:
             if skip is not None and in_mode == _lib.IN_ADD:
@@ -84,11 +130,13 @@ class _FusedBlock(nn.Module):
             else:
                 xb = BlockedTensor.from_nchw(x.contiguous())
                 sb = None if skip is None else BlockedTensor.from_nchw(skip.contiguous())
-            return layer(xb, sb, None, residual=None if residual is None else residual.contiguous())
+            outs = [layer(xb, sb, None, residual=None if residual is None else residual[:, lo:hi].contiguous())
+                    for lo, hi, layer in parts]
+            return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
         except _lib.UnetmiError as e:
             if e.code not in (_lib.E_UNSUPPORTED, _lib.E_BAD_DESC):
                 raise
-            self._blocked[halves] = False           # e.g. LDS images of this geometry exceed a CU: fp32 path from now on
+            self._blocked[halves] = (key, False)    # e.g. LDS images of this geometry exceed a CU: fp32 path from now on
             return None
 
     def _layer(self):

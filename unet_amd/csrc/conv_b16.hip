@@ -45,6 +45,7 @@ typedef __attribute__((address_space(3))) void* b16_lds_ptr;
 typedef __bf16 b16_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float b16_f32x2 __attribute__((ext_vector_type(2)));
 typedef float b16_f32x4 __attribute__((ext_vector_type(4)));
+typedef float b16_f32x4_u __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte access at element alignment
 
 __device__ __forceinline__ unsigned b16_pack2(float lo, float hi) {        // v_cvt_pk_bf16_f32: nearest-even
     return __builtin_bit_cast(unsigned, __builtin_convertvector(b16_f32x2{lo, hi}, b16_bf16x2));
@@ -688,26 +689,58 @@ __global__ __launch_bounds__(512, 2) void conv_b16_kernel_pair_rt2(const B16Args
 
 // ---- layout conversion ------------------------------------------------------------------------
 // NCHW (fp32 or bfloat16) -> blocked; a thread owns one pixel of one 8-channel block.
+// A thread owns FOUR consecutive pixels of one 8-channel block: per channel one 16-byte (fp32) or 8-byte (bfloat16)
+// load -- element alignment is enough for them -- and four 16-byte records out (64 contiguous bytes per thread).
 template <bool SRC_BF16>
 __global__ __launch_bounds__(256) void to_blocked_kernel(const void* src, const void* src2, char* dst, int C, int CB, int HW) {
-    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int pix = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int blk = blockIdx.y, n = blockIdx.z;
     if (pix >= HW) return;
-    unsigned short v[8];
+    const int np = min(4, HW - pix);
+    float f[8][4];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int c = blk * 8 + k;
-        float f = 0.f;
-        if (c < C) {
-            f = ld_act<SRC_BF16>(src, ((size_t)n * C + c) * HW + pix);
-            if (src2) f += ld_act<SRC_BF16>(src2, ((size_t)n * C + c) * HW + pix);       // summed in fp32, rounded once
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[k][q] = 0.f;
+        if (c >= C) continue;
+        const size_t base = ((size_t)n * C + c) * HW + pix;
+        if (np == 4) {
+            if constexpr (SRC_BF16) {
+                const uint2 w = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(src) + base);
+                f[k][0] = __builtin_bit_cast(float, w.x << 16); f[k][1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
+                f[k][2] = __builtin_bit_cast(float, w.y << 16); f[k][3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
+                if (src2) {
+                    const uint2 w2 = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(src2) + base);
+                    f[k][0] += __builtin_bit_cast(float, w2.x << 16); f[k][1] += __builtin_bit_cast(float, w2.x & 0xffff0000u);
+                    f[k][2] += __builtin_bit_cast(float, w2.y << 16); f[k][3] += __builtin_bit_cast(float, w2.y & 0xffff0000u);
+                }
+            } else {
+                const b16_f32x4 w = *reinterpret_cast<const b16_f32x4_u*>(static_cast<const float*>(src) + base);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[k][q] = w[q];
+                if (src2) {
+                    const b16_f32x4 w2 = *reinterpret_cast<const b16_f32x4_u*>(static_cast<const float*>(src2) + base);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) f[k][q] += w2[q];          // summed in fp32, rounded once
+                }
+            }
+        } else {
+            for (int q = 0; q < np; ++q) {
+                f[k][q] = ld_act<SRC_BF16>(src, base + q);
+                if (src2) f[k][q] += ld_act<SRC_BF16>(src2, base + q);
+            }
         }
-        v[k] = f32_to_bf16_bits(f);
     }
-    uint4 o;
-    o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
-    o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
-    *reinterpret_cast<uint4*>(dst + (((size_t)n * CB + blk) * HW + pix) * 16) = o;
+    char* o = dst + (((size_t)n * CB + blk) * HW + pix) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q >= np) break;
+        uint4 r;
+        r.x = b16_pack2(f[0][q], f[1][q]); r.y = b16_pack2(f[2][q], f[3][q]);
+        r.z = b16_pack2(f[4][q], f[5][q]); r.w = b16_pack2(f[6][q], f[7][q]);
+        *reinterpret_cast<uint4*>(o + q * 16) = r;
+    }
 }
 
 template <bool DST_BF16>
@@ -1122,7 +1155,7 @@ int unetmi_blocked_from_nchw_sum(int N, int C, int HW, const void* src, const vo
     if (!src || !dst) return api_fail(UNETMI_E_BAD_ARG, "blocked_from_nchw: null pointer");
     const int CB = 2 * ((C + 15) / 16);
     if (N > 65535 || CB > 65535) return api_fail(UNETMI_E_UNSUPPORTED, "blocked_from_nchw: N or C too large");
-    const dim3 grid((HW + 255) / 256, CB, N);
+    const dim3 grid((HW + 1023) / 1024, CB, N);              // four pixels per thread
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (src_dtype == UNETMI_DTYPE_BF16) hipLaunchKernelGGL((to_blocked_kernel<true>), grid, dim3(256), 0, st, src, src2, static_cast<char*>(dst), C, CB, HW);
     else if (src_dtype == UNETMI_DTYPE_F32) hipLaunchKernelGGL((to_blocked_kernel<false>), grid, dim3(256), 0, st, src, src2, static_cast<char*>(dst), C, CB, HW);
