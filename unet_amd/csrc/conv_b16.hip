@@ -236,7 +236,32 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
                         v[nt][r] = x * gt[r];
                     }
             }
-            if (p.out_nchw_f32) {
+            if (NT == 2 && !PAIR && p.out_nchw_f32 && p.sow == 1) {
+                // fp32 NCHW, two column tiles side by side: after the lane halves of the two tiles change places a
+                // lane holds pixel j0 + lane of channel m0' + r (first register) and of m0' + 4 + r (second), so one
+                // store instruction writes 64 consecutive pixels of one channel; the added tensor is read the same way,
+                // all eight loads of a channel quad ahead of its stores
+                const int jc = j0 + (half * 32 + j);
+                const bool okc = jc < ph.cols[0];
+                const size_t pixc = (size_t)oh * p.OW + (size_t)(jc + ph.pow_[0]);
+                const int c0 = blk * 8;                          // channels c0 + r and c0 + 4 + r
+                float* const out = static_cast<float*>(p.out);
+                float add[2][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    add[0][r] = (p.residual && okc && c0 + r < p.K) ? p.residual[((size_t)n * p.K + c0 + r) * OHW + pixc] : 0.f;
+                    add[1][r] = (p.residual && okc && c0 + 4 + r < p.K) ? p.residual[((size_t)n * p.K + c0 + 4 + r) * OHW + pixc] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    unsigned s0 = __builtin_bit_cast(unsigned, v[0][r]), s1 = __builtin_bit_cast(unsigned, v[1][r]);
+                    swap_lane_halves(s0, s1);
+                    if (okc && c0 + r < p.K)
+                        out[((size_t)n * p.K + c0 + r) * OHW + pixc] = __builtin_bit_cast(float, s0) + add[0][r];
+                    if (okc && c0 + 4 + r < p.K)
+                        out[((size_t)n * p.K + c0 + 4 + r) * OHW + pixc] = __builtin_bit_cast(float, s1) + add[1][r];
+                }
+            } else if (p.out_nchw_f32) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
