@@ -242,6 +242,31 @@ size_t unetmi_lstm_recurrence_xcd_workspace_bytes(void);
 int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wrec, const float* gx, float* hfull,
                                int channel_major, void* ws, size_t ws_bytes, void* stream);
 
+/* The projected LSTM under autograd (train() mode of ResUNet: nn.LSTM(384, 640, 3, proj_size=384), ResUNet.py:139,
+ * :186-197, whose backward the reference leaves to torch autograd).  Channel-major layouts only, H = 640, BP <= 32,
+ * same device requirements, workspace rules and status word as unetmi_lstm_recurrence_xcd.
+ *
+ * unetmi_lstm_recurrence_xcd_train: the forward recurrence that also keeps what backpropagation through time needs.
+ *   gx_gates [4H][T+1][BP]: in = input contributions (slot t+1 = step t), out = the ACTIVATED gates i, f, g, o of
+ *   every step in the same places; hfull [H][T+1][BP] as above; cell [H][T+1][BP]: c_t at slot t+1 (the caller
+ *   zeroes slot 0 of hfull and cell).  ws: unetmi_lstm_recurrence_xcd_workspace_bytes().
+ *
+ * unetmi_lstm_bptt_xcd: the reverse recurrence.  With m_t = o_t tanh(c_t) and Wrec = W_hh W_hr,
+ *   dm_t = dhfull_t + Wrec^T G_{t+1},  dc_t = dm_t o_t (1 - tanh^2 c_t) + dc_{t+1} f_{t+1},
+ *   G_t = gradient of the loss w.r.t. step t's four gate pre-activations,
+ * for t = T-1 .. 0 as ONE persistent launch (G is what the XCD's workgroups exchange per step).
+ *   gates [4H][T+1][BP]: in = what the forward call left, out = G_t at slot t+1 (slot 0 untouched);
+ *   cell as written by the forward call; dhfull [H][T+1][BP] = W_hr^T dL/dy_t at slot t+1 (one matrix product by
+ *   the caller).  The weight gradients are time-batched matrix products over G afterwards:
+ *   dW_ih = sum_t G_t x_t^T, db = sum_t G_t, dWrec = sum_t G_t m_{t-1}^T, dx_t = W_ih^T G_t.
+ *   ws: unetmi_lstm_bptt_xcd_workspace_bytes() bytes of device scratch (cleared by the call); status word
+ *   ((uint32_t*)ws)[8]; after an aborted run every G from that step down is NaN. */
+int unetmi_lstm_recurrence_xcd_train(int T, int BP, int H, const float* wrec, float* gx_gates, float* hfull,
+                                     float* cell, void* ws, size_t ws_bytes, void* stream);
+size_t unetmi_lstm_bptt_xcd_workspace_bytes(void);
+int unetmi_lstm_bptt_xcd(int T, int BP, int H, const float* wrec, float* gates, const float* cell,
+                         const float* dhfull, void* ws, size_t ws_bytes, void* stream);
+
 /* LayerNorm over the FREQUENCY axis of x[N,C,F,T] (biased variance, affine gamma/beta[F]),
  * written into channels [c_off, c_off+C) of out[N,C_out,F,T].  Replaces
  *   permute -> nn.LayerNorm(257) on [B,C,T,F] -> permute -> torch.cat       ResUNet.py:165-175, :49, :53

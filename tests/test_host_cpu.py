@@ -322,6 +322,11 @@ def test_every_entry_point_is_a_dispatcher_op_with_shape_inference():
         assert ops.conv2d_wgrad(z, None, torch.empty(2, 4, 5, 7), geom, [1, 0]).shape == (8, 4, 3, 3)
         status = ops.lstm_recurrence(torch.empty(2560, 640), torch.empty(5, 2560, 16), torch.empty(6, 640, 16), True, False)
         assert status.shape == () and status.dtype == torch.int32
+        status = ops.lstm_recurrence_train(torch.empty(2560, 640), torch.empty(2560, 6, 16), torch.empty(640, 6, 16),
+                                           torch.empty(640, 6, 16))
+        assert status.shape == () and status.dtype == torch.int32
+        status = ops.lstm_bptt(torch.empty(2560, 640), torch.empty(2560, 6, 16), torch.empty(640, 6, 16), torch.empty(640, 6, 16))
+        assert status.shape == () and status.dtype == torch.int32
         dwg, dbg = ops.dwconv2d_wgrad(z, None, z, [3, 3], [1, 2], [1, 2])
         assert dwg.shape == (8, 1, 3, 3) and dbg.shape == (8,)
         yb, mb, ib = torch.ops.unetmi.bn_act(z, c, c, None, None, 1, 1e-5, 0, None)

@@ -564,9 +564,44 @@ def test_resblock_train_step_matches_oracle(device, channels):
                                "ResBlock({}) train step".format(channels))
 
 
+@pytest.mark.parametrize("B,T,layers", [(5, 12, 3), (32, 37, 2), (37, 9, 1), (4, 501, 3)])
+def test_projected_lstm_gradients(device, B, T, layers):
+    """The projected LSTM as an autograd node (ResUNet.py:139: nn.LSTM(384, 640, 3, proj_size=384, batch_first)):
+    forward recurrence saving gates and cell states, backpropagation through time as one persistent launch per layer,
+    weight gradients as time-batched products.  Output, input gradient and all 5 parameter gradients per layer
+    against float64 autograd of torch's CPU LSTM; B=37 runs as two groups of sequences, T=501 is the benchmark's
+    sequence length."""
+    from unet_amd import lstm as L
+    torch.manual_seed(7)
+    ref = nn.LSTM(384, 640, layers, batch_first=True, proj_size=384)
+    dev_lstm = copy.deepcopy(ref).to(device)
+    ref = ref.double()
+    x = _rand((B, T, 384), 21)
+    g = _rand((B, T, 384), 22)
+    if not L.trainable_on_device(dev_lstm, x.to(device)):
+        pytest.skip("the XCD-local recurrence kernels need a device of 8 XCDs x 32 compute units")
+    x64 = x.double().requires_grad_()
+    y64 = ref(x64)[0]
+    y64.backward(g.double())
+    xd = x.to(device).requires_grad_()
+    y = L.lstm_forward_train(dev_lstm, xd)
+    assert_close(y.detach().cpu(), y64.detach().float(), tol=2e-5, what="projected LSTM output")
+    y.backward(g.to(device))
+    assert_close(xd.grad.cpu(), x64.grad.float(), tol=2e-5, what="projected LSTM input gradient")
+    exact = dict(ref.named_parameters())
+    for k, p in dev_lstm.named_parameters():
+        assert p.grad is not None, k
+        assert_close(p.grad.cpu(), exact[k].grad.float(), tol=2e-5, what="projected LSTM gradient of " + k)
+    # a second step on the same module: nothing from the first call is kept
+    for p in dev_lstm.parameters():
+        p.grad = None
+    y2 = L.lstm_forward_train(dev_lstm, xd.detach())
+    assert torch.equal(y2, y.detach())
+
+
 def test_resunet_train_step_matches_oracle(device):
     """ResUNet in train() mode (ResUNet.py:161-220 under autograd) at B=2, T=16: input layers, ResBlocks, PReLU
-    encoders / decoders, 1x1 res paths, the projected LSTM (torch's device LSTM under autograd), additive skips, head
+    encoders / decoders, 1x1 res paths, the projected LSTM (unet_amd.lstm.lstm_forward_train), additive skips, head
     and mask.  Loss, every gradient and the running statistics against the oracle."""
     import oracle
     import unet_amd

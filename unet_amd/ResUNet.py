@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .UNet_m import Decoder, Encoder, MEA, MultiScaleConvBlock, ResBlock
 from .fused import FusedConv, require_device_tensor
-from .lstm import lstm_forward, supported as lstm_supported
+from .lstm import lstm_forward, lstm_forward_train, trainable_on_device, supported as lstm_supported
 from .ops import layernorm_f, tanh_mask_mul
 
 
@@ -76,8 +76,9 @@ def _trunk(net, x, bottleneck=None):
 def _trunk_train(net, x, bottleneck=None):
     """The same trunk in train() mode, as the reference writes it (ResUNet.py:176-210): every block records autograd
     history (convolutions and BatchNorm on the library's kernels, see UNet_m._FusedBlock._run_differentiable and
-    ResBlock._forward_train), the skip adds are torch additions, and the LSTM is torch's device LSTM, whose backward
-    autograd provides (the persistent recurrence kernel is inference only)."""
+    ResBlock._forward_train), the skip adds are torch additions, and the projected LSTM is one autograd node on the
+    persistent recurrence kernels, forward and backward (unet_amd/lstm.py: lstm_forward_train; an LSTM of another
+    shape, or a device the kernels do not fit, runs torch's device LSTM)."""
     res = []
     for enc in net.encoders:
         x = enc(x)
@@ -86,7 +87,11 @@ def _trunk_train(net, x, bottleneck=None):
         y = bottleneck(x)
     else:
         seq = x.reshape(x.shape[0], x.shape[1], x.shape[3]).permute(0, 2, 1)
-        seq = net.bottleneck(seq.contiguous())[0]
+        seq = seq.contiguous()
+        if trainable_on_device(net.bottleneck, seq):
+            seq = lstm_forward_train(net.bottleneck, seq)
+        else:
+            seq = net.bottleneck(seq)[0]
         y = seq.permute(0, 2, 1).reshape(x.shape[0], x.shape[1], 1, x.shape[3])
     for i, rp in enumerate(net.res_paths):
         res[i] = rp(res[i])

@@ -49,6 +49,9 @@ EXPORTED_SYMBOLS = (
     "unetmi_lstm_recurrence",
     "unetmi_lstm_recurrence_xcd_workspace_bytes",
     "unetmi_lstm_recurrence_xcd",
+    "unetmi_lstm_recurrence_xcd_train",
+    "unetmi_lstm_bptt_xcd_workspace_bytes",
+    "unetmi_lstm_bptt_xcd",
     "unetmi_gru_recurrence",
     "unetmi_glu_fwd",
     "unetmi_instnorm_act_fwd",
@@ -139,6 +142,12 @@ def _load():
     lib.unetmi_lstm_recurrence_xcd_workspace_bytes.restype = ctypes.c_size_t
     lib.unetmi_lstm_recurrence_xcd.argtypes = [ci] * 3 + [fp] * 3 + [ci, vp, ctypes.c_size_t, vp]
     lib.unetmi_lstm_recurrence_xcd.restype = ctypes.c_int
+    lib.unetmi_lstm_recurrence_xcd_train.argtypes = [ci] * 3 + [fp] * 4 + [vp, ctypes.c_size_t, vp]
+    lib.unetmi_lstm_recurrence_xcd_train.restype = ctypes.c_int
+    lib.unetmi_lstm_bptt_xcd_workspace_bytes.argtypes = []
+    lib.unetmi_lstm_bptt_xcd_workspace_bytes.restype = ctypes.c_size_t
+    lib.unetmi_lstm_bptt_xcd.argtypes = [ci] * 3 + [fp] * 4 + [vp, ctypes.c_size_t, vp]
+    lib.unetmi_lstm_bptt_xcd.restype = ctypes.c_int
     lib.unetmi_gru_recurrence.argtypes = [ci] * 3 + [fp] * 3 + [ci, fp, vp, vp]
     lib.unetmi_gru_recurrence.restype = ctypes.c_int
     lib.unetmi_glu_fwd.argtypes = [ci] * 3 + [fp] * 3 + [ci] + [fp] * 3 + [ci, vp]

@@ -55,6 +55,8 @@ struct LstmXcdArgs {
     int T, BP;
     long long gx_step, gx_row, gx_first;      // element strides of gx per step / per gate row, offset of step 0
     long long h_step, h_row;                  // element strides of hfull per step slot / per hidden unit
+    float* gates;               // training form: the activated gates i, f, g, o of step t, laid out (and strided) as gx;
+    float* cell;                //                the cell state c_t, laid out (and strided) as hfull
 };
 
 __device__ __forceinline__ float sigmoid_x(float x) { return fast_sigmoid(x); }
@@ -65,6 +67,9 @@ __device__ __forceinline__ float dpp_add(float v) {     // v + (v moved by the D
     return v + __builtin_bit_cast(float, moved);
 }
 
+// SAVE: also keep what backpropagation through time needs -- the four activated gates of every step (written over
+// the step's input contribution: a.gates may be a.gx) and the cell state.
+template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
     __shared__ float s_h[4][kXH];                          // per wave: its quarter of the state, [k][col]
     __shared__ float s_part[2][4][kXSets][4][16];          // [parity][wave][set][gate][unit-in-set * 4 + col]
@@ -200,12 +205,193 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
             __hip_atomic_store(&hx[(size_t)((t + 1) & 1) * kXH * kXCols + (size_t)(u_base + ul) * kXCols + cj], granule,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (col_live) a.hfull[(t + 1) * a.h_step + (u_base + ul) * a.h_row + col0 + cj] = hn;
+            if (SAVE && col_live) {
+                const float gv[4] = {ig, fg, gg, og};
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    a.gates[a.gx_first + t * a.gx_step + (g * kXH + u_base + ul) * a.gx_row + col0 + cj] = gv[g];
+                a.cell[(t + 1) * a.h_step + (u_base + ul) * a.h_row + col0 + cj] = c;
+            }
         }
     }
     // Aborted at step t: every state row from that step on is NaN so that nothing computed from a state that was
     // never exchanged can pass for a result (the abort word stays raised for the caller as well).
     if (t < a.T && gate_thread && col_live)
         for (int tt = t + 1; tt <= a.T; ++tt) a.hfull[tt * a.h_step + (u_base + ul) * a.h_row + col0 + cj] = __builtin_nanf("");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backpropagation through time for the same recurrence, same placement: XCD x owns batch columns [4x, 4x+4), its 32
+// workgroups own 20 hidden units each.  With m_t = o_t * tanh(c_t) (the pre-projection state) and G_t the gradient
+// of the loss with respect to step t's four gate pre-activations,
+//     dm_t = dhfull_t + Wrec^T G_{t+1},      dc_t = dm_t * o_t * (1 - tanh^2 c_t) + dc_{t+1} * f_{t+1},
+//     G_t  = { dc_t g_t i_t(1-i_t),  dc_t c_{t-1} f_t(1-f_t),  dc_t i_t (1-g_t^2),  dm_t tanh(c_t) o_t(1-o_t) },
+// where dhfull_t = W_hr^T dL/dy_t is computed for all steps beforehand as one matrix product.  What is exchanged per
+// step is G (4H = 2560 rows x 4 columns per XCD, as {value, step} granules in the XCD's L2); a workgroup's slice of
+// Wrec^T (20 rows x 2560) stays in registers as 200 A operands per lane: wave w holds the rows of gate w, an
+// instruction's 16 blocks are 16 consecutive values of k, a block's 4 rows are 4 of the workgroup's units, its 4
+// columns the XCD's batch columns.  G_t replaces the saved gates of step t in place: the weight gradients are
+// time-batched matrix products over it afterwards.
+struct LstmXcdBwdArgs {
+    const float* wrec;          // [4H][H]
+    float* gates;               // [4H][T+1][BP]: in = activated gates of step t at slot t+1, out = G_t
+    const float* cell;          // [H][T+1][BP]: c_t at slot t+1, slot 0 = 0
+    const float* dhfull;        // [H][T+1][BP]: gradient reaching m_t through the projection, at slot t+1
+    unsigned* ctl;              // [8] tickets, [8] abort word (+ padding to 64 words)
+    unsigned long long* gxch;   // [8 XCDs][2 parities][4H][4] granules {float value, unsigned step}
+    int T, BP;
+};
+
+constexpr int kXG = 4 * kXH;             // exchanged rows per step (2560)
+constexpr int kXBKg = kXH / 16;          // k-groups per wave: 640 rows / 16 per instruction (40)
+constexpr int kXBLd = kXH * kXCols / 64; // granules a lane reads per step (40)
+
+__global__ __launch_bounds__(256, 1) void lstm_xcd_bwd_kernel(const LstmXcdBwdArgs a) {
+    __shared__ float s_g[4][kXH * kXCols];                 // per wave: its gate's rows of G, [k][col]
+    __shared__ float s_part[2][4][4][kXSets][4][4];        // [parity][wave][row of 16 lanes][set][unit][col]
+    __shared__ int s_slot;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int xcd = (int)(xcc & 7u);
+    if (tid == 0) s_slot = (int)__hip_atomic_fetch_add(&a.ctl[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int slot = s_slot;
+    const int col0 = xcd * kXCols;
+    if (slot >= kXWg || col0 >= a.BP) return;
+
+    // lane = 4*b + r: block b = value of k inside a group of 16, A operand row r = unit r of the set, B/D column r
+    const int b = lane >> 2, r = lane & 3;
+    const int u_base = slot * kXU;
+    float A[kXSets][kXBKg];
+#pragma unroll
+    for (int s = 0; s < kXSets; ++s) {
+        const float* colp = a.wrec + (size_t)(kXH * wave + b) * kXH + u_base + 4 * s + r;
+#pragma unroll
+        for (int kg = 0; kg < kXBKg; ++kg) A[s][kg] = colp[(size_t)16 * kg * kXH];
+    }
+    const bool gate_thread = tid < kXU * kXCols;
+    const int ul = tid >> 2, cj = tid & 3;
+    const bool col_live = col0 + cj < a.BP;
+    const long long row = (long long)(a.T + 1) * a.BP;
+    float dc_carry = 0.f;                                  // dc_{t+1} * f_{t+1}
+
+    unsigned long long* gx = a.gxch + (size_t)xcd * 2 * kXG * kXCols;
+    float* sg = s_g[wave];
+    bool alive = true;
+    int s = 0;
+    for (; s < a.T; ++s) {
+        const int t = a.T - 1 - s;
+        // what this step needs from the forward pass, fetched while G_{t+1} is awaited
+        float gv[4] = {0.f, 0.f, 0.f, 0.f}, c_t = 0.f, c_prev = 0.f, dm = 0.f;
+        if (gate_thread && col_live) {
+            const long long at = (long long)(t + 1) * a.BP + col0 + cj;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gv[g] = a.gates[(g * kXH + u_base + ul) * row + at];
+            c_t = a.cell[(u_base + ul) * row + at];
+            c_prev = a.cell[(u_base + ul) * row + at - a.BP];
+            dm = a.dhfull[(u_base + ul) * row + at];
+        }
+        // ---- this wave's gate of G_{t+1}: granules (640*wave + e/4, e%4), e = lane + 64*i, until all carry tag s ----
+        const unsigned long long* src = gx + (size_t)(s & 1) * kXG * kXCols + (size_t)wave * kXH * kXCols;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+            float v[kXBLd];
+#pragma unroll
+            for (int i = 0; i < kXBLd; ++i) {
+                const unsigned long long g =
+                    __hip_atomic_load(&src[lane + 64 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[i] = __builtin_bit_cast(float, (unsigned)(g & 0xffffffffull));
+                ok = ok && (unsigned)(g >> 32) == (unsigned)s;
+            }
+            if (__all(ok)) {
+#pragma unroll
+                for (int i = 0; i < kXBLd; ++i) sg[lane + 64 * i] = v[i];
+                break;
+            }
+            if ((++spins & 63u) == 0u) {
+                const unsigned stop = __hip_atomic_load(&a.ctl[kXcds], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (stop != 0u || spins > kXSpinLimit) {
+                    if (lane == 0) __hip_atomic_store(&a.ctl[kXcds], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    alive = false;
+                    break;
+                }
+            }
+        }
+        // ---- 200 MFMAs: acc[set] block b += A (Wrec[k][4 units of the set]) x B (G[k][0..3]), k = 640w + 16kg + b ----
+        f32x4 acc[kXSets];
+#pragma unroll
+        for (int q = 0; q < kXSets; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int kGrp = 8;
+        static_assert(kXBKg % kGrp == 0, "k-groups come in whole groups");
+        float bv[2][kGrp];
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q) bv[0][q] = sg[64 * q + lane];
+#pragma unroll
+        for (int gi = 0; gi < kXBKg / kGrp; ++gi) {
+            const int cur = gi & 1;
+            if (gi + 1 < kXBKg / kGrp) {
+#pragma unroll
+                for (int q = 0; q < kGrp; ++q) bv[cur ^ 1][q] = sg[64 * ((gi + 1) * kGrp + q) + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < kGrp; ++q)
+#pragma unroll
+                for (int st = 0; st < kXSets; ++st)
+                    acc[st] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[st][gi * kGrp + q], bv[cur][q], acc[st], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // sum the 4 blocks inside each row of 16 lanes; the 4 rows and the 4 waves meet in LDS
+        float* part = &s_part[s & 1][wave][lane >> 4][0][0][0];
+#pragma unroll
+        for (int st = 0; st < kXSets; ++st)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x = acc[st][i];
+                x = dpp_add<0x128>(x);          // row_ror:8
+                x = dpp_add<0x124>(x);          // row_ror:4
+                if ((lane & 12) == 0) part[(st * 4 + i) * 4 + r] = x;
+            }
+        if (!__syncthreads_and(alive ? 1 : 0)) break;
+        // ---- this step's gate gradients ----
+        if (gate_thread) {
+            const int st = ul >> 2, i = ul & 3;
+            float back = 0.f;                              // (Wrec^T G_{t+1})[unit][col], summed in a fixed order
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float pw = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pw += s_part[s & 1][w][q][st][i][cj];
+                back += pw;
+            }
+            const float dmv = dm + back;
+            const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+            const float tc = fast_tanh(c_t);
+            const float dc = dmv * og * (1.f - tc * tc) + dc_carry;
+            dc_carry = dc * fg;
+            float G[4] = {dc * gg * ig * (1.f - ig), dc * c_prev * fg * (1.f - fg), dc * ig * (1.f - gg * gg),
+                          dmv * tc * og * (1.f - og)};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float val = col_live ? G[g] : 0.f;
+                const unsigned long long granule =
+                    (unsigned long long)__builtin_bit_cast(unsigned, val) | ((unsigned long long)(unsigned)(s + 1) << 32);
+                __hip_atomic_store(&gx[(size_t)((s + 1) & 1) * kXG * kXCols + (size_t)(g * kXH + u_base + ul) * kXCols + cj],
+                                   granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (col_live) a.gates[(g * kXH + u_base + ul) * row + (long long)(t + 1) * a.BP + col0 + cj] = val;
+            }
+        }
+    }
+    // Aborted: every gradient from that step down is NaN (the abort word stays raised for the caller as well).
+    if (s < a.T && gate_thread && col_live)
+        for (int ss = s; ss < a.T; ++ss)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                a.gates[(g * kXH + u_base + ul) * row + (long long)(a.T - ss) * a.BP + col0 + cj] = __builtin_nanf("");
 }
 
 }  // namespace unetmi
@@ -216,8 +402,22 @@ extern "C" size_t unetmi_lstm_recurrence_xcd_workspace_bytes(void) {
     return 64 * sizeof(unsigned) + (size_t)kXcds * 2 * kXH * kXCols * sizeof(unsigned long long);
 }
 
+static int lstm_xcd_run(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, int channel_major,
+                        float* gates, float* cell, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wrec, const float* gx, float* hfull,
                                           int channel_major, void* ws, size_t ws_bytes, void* stream) {
+    return lstm_xcd_run(T, BP, H, wrec, gx, hfull, channel_major, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int unetmi_lstm_recurrence_xcd_train(int T, int BP, int H, const float* wrec, float* gx_gates, float* hfull,
+                                                float* cell, void* ws, size_t ws_bytes, void* stream) {
+    if (!cell) return api_fail(UNETMI_E_BAD_ARG, "lstm_recurrence_xcd_train: null pointer");
+    return lstm_xcd_run(T, BP, H, wrec, gx_gates, hfull, 1, gx_gates, cell, ws, ws_bytes, stream);
+}
+
+static int lstm_xcd_run(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, int channel_major,
+                        float* gates, float* cell, void* ws, size_t ws_bytes, void* stream) {
     if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence_xcd: bad sizes");
     if (channel_major != 0 && channel_major != 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence_xcd: layout is 0 or 1");
     if (H != kXH) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: built for hidden size 640");
@@ -232,11 +432,13 @@ extern "C" int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wre
     // one workgroup per compute unit, 32 compute units on each of 8 XCDs
     if (cus != kXcds * kXWg) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: needs 8 XCDs of 32 compute units");
     int per_cu = 0;
-    const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_kernel, 256, 0);
+    const hipError_t oe = gates ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_kernel<true>, 256, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_kernel<false>, 256, 0);
     if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd occupancy query: ") + hipGetErrorString(oe));
     if (per_cu < 1) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: the kernel does not fit a compute unit");
     LstmXcdArgs a{};
     a.wrec = wrec; a.gx = gx; a.hfull = hfull; a.T = T; a.BP = BP;
+    a.gates = gates; a.cell = cell;
     if (channel_major) {        // [rows][T+1][BP]: slot 0 of both is the state before the first step
         a.gx_step = BP; a.gx_row = (long long)(T + 1) * BP; a.gx_first = BP;
         a.h_step = BP; a.h_row = (long long)(T + 1) * BP;
@@ -250,7 +452,41 @@ extern "C" int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wre
     // tickets, abort word and the state granules start from zero: h_0 = 0 carrying step tag 0
     hipError_t e = hipMemsetAsync(ws, 0, unetmi_lstm_recurrence_xcd_workspace_bytes(), s);
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd memset: ") + hipGetErrorString(e));
-    hipLaunchKernelGGL(lstm_xcd_kernel, dim3(kXcds * kXWg), dim3(256), 0, s, a);
+    if (gates) hipLaunchKernelGGL(lstm_xcd_kernel<true>, dim3(kXcds * kXWg), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lstm_xcd_kernel<false>, dim3(kXcds * kXWg), dim3(256), 0, s, a);
     e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd launch: ") + hipGetErrorString(e));
+}
+
+extern "C" size_t unetmi_lstm_bptt_xcd_workspace_bytes(void) {
+    return 64 * sizeof(unsigned) + (size_t)kXcds * 2 * kXG * kXCols * sizeof(unsigned long long);
+}
+
+extern "C" int unetmi_lstm_bptt_xcd(int T, int BP, int H, const float* wrec, float* gates, const float* cell,
+                                    const float* dhfull, void* ws, size_t ws_bytes, void* stream) {
+    if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_bptt_xcd: bad sizes");
+    if (H != kXH) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_bptt_xcd: built for hidden size 640");
+    if (BP > kXcds * kXCols) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_bptt_xcd: at most 32 batch columns per launch");
+    if (T == 0) return UNETMI_OK;
+    if (!wrec || !gates || !cell || !dhfull || !ws) return api_fail(UNETMI_E_BAD_ARG, "lstm_bptt_xcd: null pointer");
+    if (ws_bytes < unetmi_lstm_bptt_xcd_workspace_bytes()) return api_fail(UNETMI_E_BAD_ARG, "lstm_bptt_xcd: workspace too small");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return api_fail(UNETMI_E_HIP, "lstm_bptt_xcd: cannot query the device");
+    if (cus != kXcds * kXWg) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_bptt_xcd: needs 8 XCDs of 32 compute units");
+    int per_cu = 0;
+    const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_bwd_kernel, 256, 0);
+    if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_bptt_xcd occupancy query: ") + hipGetErrorString(oe));
+    if (per_cu < 1) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_bptt_xcd: the kernel does not fit a compute unit");
+    LstmXcdBwdArgs a{};
+    a.wrec = wrec; a.gates = gates; a.cell = cell; a.dhfull = dhfull; a.T = T; a.BP = BP;
+    a.ctl = static_cast<unsigned*>(ws);
+    a.gxch = reinterpret_cast<unsigned long long*>(static_cast<unsigned*>(ws) + 64);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // tickets, abort word and the granules start from zero: G_T = 0 carrying tag 0
+    hipError_t e = hipMemsetAsync(ws, 0, unetmi_lstm_bptt_xcd_workspace_bytes(), s);
+    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_bptt_xcd memset: ") + hipGetErrorString(e));
+    hipLaunchKernelGGL(lstm_xcd_bwd_kernel, dim3(kXcds * kXWg), dim3(256), 0, s, a);
+    e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_bptt_xcd launch: ") + hipGetErrorString(e));
 }

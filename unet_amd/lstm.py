@@ -6,6 +6,10 @@ kernel they are 1x1 convolutions of the library's own kernel on a [channels, T+1
 the recurrence kernel reads and writes directly (``GEMM = "conv"``); the device-wide-barrier kernel
 keeps the step-major layout and torch.matmul.  The recurrence itself is one persistent HIP launch per
 layer (unetmi_lstm_recurrence_xcd / unetmi_lstm_recurrence) instead of three launches per time step.
+
+Under autograd (``lstm_forward_train``; train() mode of ResUNet) the forward recurrence also keeps the activated
+gates and the cell states, and backpropagation through time is ONE persistent launch per layer as well
+(unetmi_lstm_bptt_xcd) between time-batched matrix products for the weight and input gradients.
 """
 
 import torch
@@ -159,3 +163,108 @@ def lstm_forward(lstm, x, cache, _force_grid=False):
         # a recurrence that gave up waiting (GPU shared with other work) must not pass for a result: the whole
         # output becomes NaN, without a host round trip
         return torch.where(aborted != 0, torch.full_like(out, float("nan")), out)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# train() mode: the same layer stack as an autograd node
+# ------------------------------------------------------------------------------------------------------------
+PARAMS_PER_LAYER = ("weight_ih_l{}", "weight_hh_l{}", "bias_ih_l{}", "bias_hh_l{}", "weight_hr_l{}")
+
+
+def trainable_on_device(lstm, x):
+    """lstm_forward_train serves this call: a projected LSTM of hidden size 640 on a device the XCD-local kernels
+    fit (H = 300 and other devices keep torch's device LSTM under autograd)."""
+    return (supported(lstm) and lstm.hidden_size == 640 and x.is_cuda and x.dtype == torch.float32
+            and _xcd_kernel_fits(x.device, lstm.hidden_size))
+
+
+class RecurrenceAborted(RuntimeError):
+    """A persistent recurrence kernel gave up waiting for a workgroup that was not resident."""
+
+
+class _ProjectedLstm(torch.autograd.Function):
+    """x [B<=32, T, C] and the 5 parameters of every layer -> (y [B, T, proj], status).  Every tensor of the stack is
+    [channels, T+1, BP] (slot 0 = the time before the first step)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        B, T, C = x.shape
+        L = len(params) // 5
+        BP = (B + 15) // 16 * 16
+        dev = x.device
+        with torch.cuda.device(dev):
+            seq = torch.zeros((C, T + 1, BP), dtype=torch.float32, device=dev)
+            seq[:, 1:, :B] = x.detach().permute(2, 1, 0)
+            status = torch.zeros((), dtype=torch.int32, device=dev)
+            saved = []
+            for layer in range(L):
+                w_ih, w_hh, b_ih, b_hh, w_hr = (p.detach() for p in params[5 * layer:5 * layer + 5])
+                H = w_hh.shape[0] // 4
+                gates = torch.addmm((b_ih + b_hh)[:, None], w_ih, seq.view(seq.shape[0], -1)).view(4 * H, T + 1, BP)
+                wrec = (w_hh.double() @ w_hr.double()).float().contiguous()
+                hfull = torch.empty((H, T + 1, BP), dtype=torch.float32, device=dev)
+                cell = torch.empty((H, T + 1, BP), dtype=torch.float32, device=dev)
+                hfull[:, 0].zero_()
+                cell[:, 0].zero_()
+                status = status | _ops.lstm_recurrence_train(wrec, gates, hfull, cell)
+                saved += [seq, gates, hfull, cell, wrec]
+                seq = (w_hr @ hfull.view(H, -1)).view(w_hr.shape[0], T + 1, BP)
+            out = seq[:, 1:, :B].permute(2, 1, 0).contiguous()
+        ctx.save_for_backward(*params, *saved)
+        ctx.dims = (B, T, BP, L)
+        ctx.mark_non_differentiable(status)
+        return out, status
+
+    @staticmethod
+    def backward(ctx, dout, _dstatus):
+        B, T, BP, L = ctx.dims
+        params, saved = ctx.saved_tensors[:5 * L], ctx.saved_tensors[5 * L:]
+        dev = dout.device
+        grads = [None] * (5 * L)
+        with torch.cuda.device(dev):
+            dy = torch.zeros((dout.shape[2], T + 1, BP), dtype=torch.float32, device=dev)
+            dy[:, 1:, :B] = dout.permute(2, 1, 0)
+            status = torch.zeros((), dtype=torch.int32, device=dev)
+            for layer in reversed(range(L)):
+                w_ih, w_hh, _, _, w_hr = (p.detach() for p in params[5 * layer:5 * layer + 5])
+                seq, gates, hfull, cell, wrec = saved[5 * layer:5 * layer + 5]
+                H = hfull.shape[0]
+                Y, M, X = dy.view(dy.shape[0], -1), hfull.view(H, -1), seq.view(seq.shape[0], -1)
+                dhfull = (w_hr.t() @ Y).view(H, T + 1, BP)
+                d_w_hr = Y[:, BP:] @ M[:, BP:].t()                       # through y_t = W_hr m_t
+                # the gates become the gradients of the gate pre-activations in place (a second backward through
+                # this node would need them again: retain_graph is not supported)
+                status = status | _ops.lstm_bptt(wrec, gates, cell, dhfull)
+                G = gates.view(4 * H, -1)
+                Gs = G[:, BP:]                                           # steps 0..T-1 (slot 0 is not a step)
+                d_wrec = Gs @ M[:, :-BP].t()                             # G_t m_{t-1}^T
+                grads[5 * layer + 0] = Gs @ X[:, BP:].t()
+                grads[5 * layer + 1] = d_wrec @ w_hr.t()
+                grads[5 * layer + 2] = Gs.sum(dim=1)
+                grads[5 * layer + 3] = grads[5 * layer + 2].clone()
+                grads[5 * layer + 4] = d_w_hr + w_hh.t() @ d_wrec
+                dy = (w_ih.t() @ G).view(w_ih.shape[1], T + 1, BP)       # slot 0 holds no step and is never read
+            dx = dy[:, 1:, :B].permute(2, 1, 0).contiguous()
+            if int(status.item()) != 0:
+                raise RecurrenceAborted("unet_amd.lstm: the reverse recurrence kernel gave up waiting for a workgroup "
+                                        "that was not resident (GPU shared with other work?)")
+        return (dx, *grads)
+
+
+def lstm_forward_train(lstm, x):
+    """x [B, T, input] -> [B, T, proj] with autograd history: gradients reach x and every parameter of ``lstm``.
+    Zero initial state.  Falls back to torch's LSTM for a call whose forward kernel reports an abort."""
+    if not trainable_on_device(lstm, x):
+        raise NotImplementedError("lstm_forward_train: a projected fp32 LSTM of hidden size 640 on a 256-CU device")
+    B = x.shape[0]
+    if B > XCD_BATCH_PER_LAUNCH:                    # sequences are independent: run them in groups
+        return torch.cat([lstm_forward_train(lstm, x[i:i + XCD_BATCH_PER_LAUNCH])
+                          for i in range(0, B, XCD_BATCH_PER_LAUNCH)], dim=0)
+    params = [getattr(lstm, name.format(layer)) for layer in range(lstm.num_layers) for name in PARAMS_PER_LAYER]
+    out, status = _ProjectedLstm.apply(x.contiguous(), *params)
+    if int(status.item()) != 0:
+        import warnings
+        warnings.warn("unet_amd.lstm: the XCD-local recurrence kernel gave up waiting for a workgroup that was not "
+                      "resident (GPU shared with other work?); running this call on torch's LSTM")
+        return lstm(x)[0]
+    return out

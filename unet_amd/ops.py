@@ -411,6 +411,8 @@ _LIBRARY.define("adam_step(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Te
 _LIBRARY.define("gather_f32(Tensor src, Tensor map) -> Tensor")
 _LIBRARY.define("dwconv2d_wgrad(Tensor x, Tensor? x2, Tensor dout, int[] kernel, int[] padding, int[] dilation) -> (Tensor, Tensor)")
 _LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool xcd, bool channel_major) -> Tensor")
+_LIBRARY.define("lstm_recurrence_train(Tensor wrec, Tensor(a!) gx, Tensor(b!) hfull, Tensor(c!) cell) -> Tensor")
+_LIBRARY.define("lstm_bptt(Tensor wrec, Tensor(a!) gates, Tensor cell, Tensor dhfull) -> Tensor")
 _LIBRARY.define("gru_recurrence(Tensor whh, Tensor bhh, Tensor gx, Tensor(a!) hfull, bool channel_major) -> Tensor")
 _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
 _LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
@@ -609,6 +611,48 @@ def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major):
         return sync[-1].clone()
 
 
+def _lstm_train_shapes(op, wrec, gates, others):
+    for t, name in ((wrec, "wrec"), (gates, "gates")) + tuple(others):
+        _dev(t, name, op)
+    G, Tp, BP = gates.shape
+    H = G // 4
+    if G != 4 * H or tuple(wrec.shape) != (G, H) or any(tuple(t.shape) != (H, Tp, BP) for t, _ in others):
+        raise ValueError("unetmi::{}: wrec [4H,H], gates [4H,T+1,BP] and [H,T+1,BP] state tensors expected".format(op))
+    return Tp - 1, BP, H
+
+
+def _lstm_recurrence_train_cuda(wrec, gx, hfull, cell):
+    """The XCD-local forward recurrence on channel-major tensors, keeping the activated gates (written over gx) and
+    the cell states for lstm_bptt.  Returns the status word."""
+    T, BP, H = _lstm_train_shapes("lstm_recurrence_train", wrec, gx, ((hfull, "hfull"), (cell, "cell")))
+    with torch.cuda.device(gx.device):
+        stream = _stream(gx)
+        key = (gx.device, stream, True, H)
+        nbytes = _lib.lib.unetmi_lstm_recurrence_xcd_workspace_bytes()
+        ws = _lstm_scratch.get(key)
+        if ws is None:
+            ws = _lstm_scratch[key] = torch.empty(nbytes // 4, dtype=torch.int32, device=gx.device)
+        check(_lib.lib.unetmi_lstm_recurrence_xcd_train(T, BP, H, _ptr(wrec), _ptr(gx), _ptr(hfull), _ptr(cell), _ptr(ws),
+                                                        nbytes, stream), "unetmi_lstm_recurrence_xcd_train")
+        return ws[8].clone()
+
+
+def _lstm_bptt_cuda(wrec, gates, cell, dhfull):
+    """The reverse recurrence: gates [4H, T+1, BP] (as lstm_recurrence_train left them) become the gradients of the
+    gate pre-activations in place.  Returns the status word."""
+    T, BP, H = _lstm_train_shapes("lstm_bptt", wrec, gates, ((cell, "cell"), (dhfull, "dhfull")))
+    with torch.cuda.device(gates.device):
+        stream = _stream(gates)
+        key = (gates.device, stream, "bptt", H)
+        nbytes = _lib.lib.unetmi_lstm_bptt_xcd_workspace_bytes()
+        ws = _lstm_scratch.get(key)
+        if ws is None:
+            ws = _lstm_scratch[key] = torch.empty(nbytes // 4, dtype=torch.int32, device=gates.device)
+        check(_lib.lib.unetmi_lstm_bptt_xcd(T, BP, H, _ptr(wrec), _ptr(gates), _ptr(cell), _ptr(dhfull), _ptr(ws), nbytes,
+                                            stream), "unetmi_lstm_bptt_xcd")
+        return ws[8].clone()
+
+
 def _dwconv2d_wgrad_cuda(x, x2, dout, kernel, padding, dilation):
     """(dweight [C,1,kh,kw], dbias [C]) of the depthwise 'same' convolution that dwconv2d_fwd computes."""
     _dev(x, "x", "dwconv2d_wgrad"), _dev(dout, "dout", "dwconv2d_wgrad")
@@ -792,7 +836,8 @@ def _conv2d_b16_head_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_
 for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_batch_stats", _bn_batch_stats_cuda),
                    ("bn_running_update", _bn_running_update_cuda), ("bn_act_fwd", _bn_act_fwd_cuda),
                    ("bn_act_bwd", _bn_act_bwd_cuda), ("conv2d_wgrad", _conv2d_wgrad_cuda),
-                   ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda), ("gru_recurrence", _gru_recurrence_cuda), ("dwconv2d_wgrad", _dwconv2d_wgrad_cuda),
+                   ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda),
+                   ("lstm_recurrence_train", _lstm_recurrence_train_cuda), ("lstm_bptt", _lstm_bptt_cuda), ("gru_recurrence", _gru_recurrence_cuda), ("dwconv2d_wgrad", _dwconv2d_wgrad_cuda),
                    ("blocked_from_nchw", _blocked_from_nchw_cuda), ("nchw_from_blocked", _nchw_from_blocked_cuda),
                    ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda), ("conv2d_b16_head_fwd", _conv2d_b16_head_fwd_cuda),
                    ("conv2d_b16_nchw_fwd", _conv2d_b16_nchw_fwd_cuda), ("blocked_from_nchw_sum", _blocked_from_nchw_sum_cuda)):
@@ -844,6 +889,16 @@ def _(src, map):
 @torch.library.register_fake("unetmi::lstm_recurrence")
 def _(wrec, gx, hfull, xcd, channel_major):
     return gx.new_empty((), dtype=torch.int32)
+
+
+@torch.library.register_fake("unetmi::lstm_recurrence_train")
+def _(wrec, gx, hfull, cell):
+    return gx.new_empty((), dtype=torch.int32)
+
+
+@torch.library.register_fake("unetmi::lstm_bptt")
+def _(wrec, gates, cell, dhfull):
+    return gates.new_empty((), dtype=torch.int32)
 
 
 @torch.library.register_fake("unetmi::dwconv2d_wgrad")
@@ -910,6 +965,8 @@ conv2d_wgrad = torch.ops.unetmi.conv2d_wgrad
 adam_step = torch.ops.unetmi.adam_step
 gather_f32 = torch.ops.unetmi.gather_f32
 lstm_recurrence = torch.ops.unetmi.lstm_recurrence
+lstm_recurrence_train = torch.ops.unetmi.lstm_recurrence_train
+lstm_bptt = torch.ops.unetmi.lstm_bptt
 gru_recurrence = torch.ops.unetmi.gru_recurrence
 dwconv2d_wgrad = torch.ops.unetmi.dwconv2d_wgrad
 blocked_from_nchw = torch.ops.unetmi.blocked_from_nchw
