@@ -226,6 +226,24 @@ int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float*
 int unetmi_gru_recurrence(int T, int BP, int H, const float* whh, const float* bhh, const float* gx,
                           int gx_channel_major, float* hfull, void* sync_ws, void* stream);
 
+/* The GRU under autograd (train() mode of the TGRU bottlenecks and of cRNN, DSUNet.py:281-312, UDSS.py:39-70, :190-239;
+ * the reference leaves the backward to torch autograd).  Step-major layouts, sizes and sync_ws as unetmi_gru_recurrence.
+ *
+ * unetmi_gru_recurrence_train: the forward recurrence that also fills gates [T][4H][BP] with r, z, q = W_hn h + b_hn
+ *   and n of every step (rows g*H + u in that order).
+ *
+ * unetmi_gru_bptt: the reverse recurrence as ONE persistent launch.  dy [T][H][BP] = gradient of the loss w.r.t. the
+ *   outputs h_1..h_T (the gradient of the final state, if any, added to the last step by the caller).  gates is
+ *   overwritten in place: rows [0, 3H) become the gradient w.r.t. W_hh h + b_hh (gates r, z, n), rows [0, 2H) and
+ *   [3H, 4H) the gradient w.r.t. W_ih x + b_ih, so that  dW_hh = sum_t G_t[0:3H] h_{t-1}^T,
+ *   dW_ih = sum_t G_t[0:2H, 3H:4H] x_t^T  and  dx_t = W_ih^T G_t[0:2H, 3H:4H]  are time-batched products afterwards;
+ *   dh0 [H][BP] receives the gradient reaching the initial state.  H/16 workgroups, all resident at once (checked);
+ *   after an aborted run (last word of sync_ws non-zero) every gradient from that step down is NaN. */
+int unetmi_gru_recurrence_train(int T, int BP, int H, const float* whh, const float* bhh, const float* gx,
+                                float* hfull, float* gates, void* sync_ws, void* stream);
+int unetmi_gru_bptt(int T, int BP, int H, const float* whh, float* gates, const float* hfull, const float* dy,
+                    float* dh0, void* sync_ws, void* stream);
+
 /* The same recurrence with the batch split over the chip's 8 XCDs (4 batch columns each, BP <= 32): every XCD runs
  * an independent recurrence for its columns, the state exchange stays inside that XCD's L2 and there is no
  * device-wide barrier (about 2 us per step instead of 6-7).  Arguments and results as unetmi_lstm_recurrence.

@@ -333,6 +333,11 @@ def test_every_entry_point_is_a_dispatcher_op_with_shape_inference():
         assert yb.shape == z.shape and mb.shape == ib.shape == (8,)
         status = ops.gru_recurrence(torch.empty(384, 128), torch.empty(384), torch.empty(5, 384, 16), torch.empty(6, 128, 16), False)
         assert status.shape == () and status.dtype == torch.int32
+        status = ops.gru_recurrence_train(torch.empty(384, 128), torch.empty(384), torch.empty(5, 384, 16), torch.empty(6, 128, 16),
+                                          torch.empty(5, 512, 16))
+        assert status.shape == () and status.dtype == torch.int32
+        dh0, status = ops.gru_bptt(torch.empty(384, 128), torch.empty(5, 512, 16), torch.empty(6, 128, 16), torch.empty(5, 128, 16))
+        assert dh0.shape == (128, 16) and status.shape == () and status.dtype == torch.int32
         b = ops.blocked_from_nchw(z)
         assert b.shape == (2, 2, 5, 7, 8) and b.dtype == torch.bfloat16
         assert ops.nchw_from_blocked(b, 8, True).dtype == torch.float32

@@ -599,6 +599,40 @@ def test_projected_lstm_gradients(device, B, T, layers):
     assert torch.equal(y2, y.detach())
 
 
+@pytest.mark.parametrize("C,H,B,T,with_h0", [(128, 128, 5, 19, False), (128, 128, 48, 33, True), (256, 512, 3, 11, True),
+                                               (256, 256, 70, 7, False), (128, 128, 2, 512, False)])
+def test_gru_gradients(device, C, H, B, T, with_h0):
+    """nn.GRU as an autograd node on the persistent kernels (DSUNet.py:281-312 TGRUBlock GRU(128,128); UDSS.py:39-70
+    GRU(256,512); UDSS.py:190-239 GRU(256,256)): outputs, final state, input / initial-state gradients and the four
+    parameter gradients against float64 autograd of torch's CPU GRU.  The loss uses the outputs AND the final state;
+    B=70 runs as two groups of sequences, T=512 is DSUNet's full sequence length."""
+    from unet_amd import gru as G
+    torch.manual_seed(11)
+    ref = nn.GRU(C, H, 1, batch_first=True)
+    dev_gru = copy.deepcopy(ref).to(device).train()
+    ref = ref.double()
+    x, g, gh = _rand((B, T, C), 31), _rand((B, T, H), 32), _rand((1, B, H), 33)
+    h0 = _rand((1, B, H), 34, 0.5) if with_h0 else None
+    x64 = x.double().requires_grad_()
+    h64 = h0.double().requires_grad_() if with_h0 else None
+    y64, hn64 = ref(x64, h64)
+    ((y64 * g.double()).sum() + (hn64 * gh.double()).sum()).backward()
+    xd = x.to(device).requires_grad_()
+    hd = h0.to(device).requires_grad_() if with_h0 else None
+    y, hn = G.run(dev_gru, xd, hd)
+    assert y.grad_fn is not None and "Gru" in type(y.grad_fn).__name__ or B > 64, type(y.grad_fn)
+    assert_close(y.detach().cpu(), y64.detach().float(), tol=2e-5, what="GRU output")
+    assert_close(hn.detach().cpu(), hn64.detach().float(), tol=2e-5, what="GRU final state")
+    ((y * g.to(device)).sum() + (hn * gh.to(device)).sum()).backward()
+    assert_close(xd.grad.cpu(), x64.grad.float(), tol=2e-5, what="GRU input gradient")
+    if with_h0:
+        assert_close(hd.grad.cpu(), h64.grad.float(), tol=2e-5, what="GRU initial-state gradient")
+    exact = dict(ref.named_parameters())
+    for k, p in dev_gru.named_parameters():
+        assert p.grad is not None, k
+        assert_close(p.grad.cpu(), exact[k].grad.float(), tol=2e-5, what="GRU gradient of " + k)
+
+
 def test_resunet_train_step_matches_oracle(device):
     """ResUNet in train() mode (ResUNet.py:161-220 under autograd) at B=2, T=16: input layers, ResBlocks, PReLU
     encoders / decoders, 1x1 res paths, the projected LSTM (unet_amd.lstm.lstm_forward_train), additive skips, head

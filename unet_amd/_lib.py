@@ -53,6 +53,8 @@ EXPORTED_SYMBOLS = (
     "unetmi_lstm_bptt_xcd_workspace_bytes",
     "unetmi_lstm_bptt_xcd",
     "unetmi_gru_recurrence",
+    "unetmi_gru_recurrence_train",
+    "unetmi_gru_bptt",
     "unetmi_glu_fwd",
     "unetmi_instnorm_act_fwd",
     "unetmi_conv2d_b16_packed_weight_bytes",
@@ -150,6 +152,10 @@ def _load():
     lib.unetmi_lstm_bptt_xcd.restype = ctypes.c_int
     lib.unetmi_gru_recurrence.argtypes = [ci] * 3 + [fp] * 3 + [ci, fp, vp, vp]
     lib.unetmi_gru_recurrence.restype = ctypes.c_int
+    lib.unetmi_gru_recurrence_train.argtypes = [ci] * 3 + [fp] * 5 + [vp, vp]
+    lib.unetmi_gru_recurrence_train.restype = ctypes.c_int
+    lib.unetmi_gru_bptt.argtypes = [ci] * 3 + [fp] * 5 + [vp, vp]
+    lib.unetmi_gru_bptt.restype = ctypes.c_int
     lib.unetmi_glu_fwd.argtypes = [ci] * 3 + [fp] * 3 + [ci] + [fp] * 3 + [ci, vp]
     lib.unetmi_glu_fwd.restype = ctypes.c_int
     lib.unetmi_instnorm_act_fwd.argtypes = [ci] * 3 + [fp] * 3 + [cf, ci, fp, ci, fp, fp, ci, vp]

@@ -3,8 +3,10 @@ the four GRUs of UDSS.py:190-239's cRNN).
 
 The input contribution of all time steps is one matrix product before the recurrence (a 1x1 convolution of the
 library's own kernel); the recurrence itself is one
-persistent HIP launch (unetmi_gru_recurrence) instead of several launches per time step.  Eval mode only (no
-autograd graph is recorded); a GRU in train mode stays on torch's device RNN.
+persistent HIP launch (unetmi_gru_recurrence) instead of several launches per time step.  In eval mode no autograd
+graph is recorded; a GRU in train mode is one autograd node (``gru_forward_train``): the forward recurrence keeps
+the gates, backpropagation through time is one persistent launch as well (unetmi_gru_bptt), and the weight and input
+gradients are time-batched matrix products over its result.
 """
 
 import weakref
@@ -23,12 +25,16 @@ MAX_GROUPS = 8                    # beyond this many launches per call (batch > 
                                   # numerous (the frequency-axis GRU): torch's batched RNN serves those
 
 
-def supported(gru, x=None):
+def _shape_supported(gru, x=None):
     ok = (isinstance(gru, nn.GRU) and gru.hidden_size in (128, 256, 512) and gru.num_layers == 1 and gru.batch_first
-          and not gru.bidirectional and gru.bias and not gru.training)
+          and not gru.bidirectional and gru.bias)
     if ok and x is not None:
         ok = x.is_cuda and x.dim() == 3 and x.shape[0] <= MAX_BATCH_PER_LAUNCH * MAX_GROUPS
     return ok
+
+
+def supported(gru, x=None):
+    return _shape_supported(gru, x) and not gru.training
 
 
 def gru_forward(gru, x, h0=None):
@@ -76,8 +82,90 @@ def gru_forward(gru, x, h0=None):
         return y, y[:, -1].unsqueeze(0).contiguous() if T > 0 else hfull[0, :, :B].t().unsqueeze(0).contiguous()
 
 
+class RecurrenceAborted(RuntimeError):
+    """A persistent recurrence kernel gave up waiting for a workgroup that was not resident."""
+
+
+class _Gru(torch.autograd.Function):
+    """(x [B<=64, T, C], h0 [B, H], w_ih, w_hh, b_ih, b_hh) -> (y [B, T, H], status); step-major tensors [T, rows, BP]."""
+
+    @staticmethod
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh):
+        B, T, C = x.shape
+        H = w_hh.shape[1]
+        BP = (B + 15) // 16 * 16
+        dev = x.device
+        with torch.cuda.device(dev):
+            seq = torch.zeros((T, C, BP), dtype=torch.float32, device=dev)
+            seq[:, :, :B] = x.detach().permute(1, 2, 0)
+            gx = (torch.matmul(w_ih.detach(), seq) + b_ih.detach()[None, :, None]).contiguous()
+            hfull = torch.empty((T + 1, H, BP), dtype=torch.float32, device=dev)
+            hfull[0].zero_()
+            hfull[0, :, :B] = h0.detach().t()
+            gates = torch.empty((T, 4 * H, BP), dtype=torch.float32, device=dev)
+            status = _ops.gru_recurrence_train(w_hh.detach().contiguous(), b_hh.detach().contiguous(), gx, hfull, gates)
+            y = hfull[1:, :, :B].permute(2, 0, 1).contiguous()
+        ctx.save_for_backward(w_ih, w_hh, seq, hfull, gates)
+        ctx.dims = (B, T, C, H, BP)
+        ctx.mark_non_differentiable(status)
+        return y, status
+
+    @staticmethod
+    def backward(ctx, dy, _dstatus):
+        B, T, C, H, BP = ctx.dims
+        w_ih, w_hh, seq, hfull, gates = ctx.saved_tensors
+        dev = dy.device
+        with torch.cuda.device(dev):
+            dyp = torch.zeros((T, H, BP), dtype=torch.float32, device=dev)
+            dyp[:, :, :B] = dy.permute(1, 2, 0)
+            # the gates become the pre-activation gradients in place (no second backward through this node)
+            dh0, status = _ops.gru_bptt(w_hh.detach().contiguous(), gates, hfull, dyp)
+            if int(status.item()) != 0:
+                raise RecurrenceAborted("unet_amd.gru: the reverse recurrence kernel gave up waiting for a workgroup "
+                                        "that was not resident (GPU shared with other work?)")
+            G = gates.permute(1, 0, 2).reshape(4 * H, T * BP)
+            hprev = hfull[:T].permute(1, 0, 2).reshape(H, T * BP)
+            X = seq.permute(1, 0, 2).reshape(C, T * BP)
+            g_hh = G[:3 * H]                                          # w.r.t. W_hh h + b_hh
+            g_ih = torch.cat([G[:2 * H], G[3 * H:]], dim=0)           # w.r.t. W_ih x + b_ih
+            d_w_hh, d_b_hh = g_hh @ hprev.t(), g_hh.sum(dim=1)
+            d_w_ih, d_b_ih = g_ih @ X.t(), g_ih.sum(dim=1)
+            dx = (w_ih.detach().t() @ g_ih).view(C, T, BP)[:, :, :B].permute(2, 1, 0).contiguous()
+        return dx, dh0[:, :B].t().contiguous(), d_w_ih, d_w_hh, d_b_ih, d_b_hh
+
+
+def gru_forward_train(gru, x, h0=None):
+    """nn.GRU's call with autograd history on the persistent kernels: gradients reach x, h0 and the four parameters."""
+    if not (_shape_supported(gru, x) and x.dtype == torch.float32):
+        raise NotImplementedError("gru_forward_train: a single-layer unidirectional batch_first fp32 GRU with hidden "
+                                  "size 128, 256 or 512 on the device")
+    B = x.shape[0]
+    H = gru.hidden_size
+    if B > MAX_BATCH_PER_LAUNCH:
+        ys, hs = [], []
+        for i in range(0, B, MAX_BATCH_PER_LAUNCH):
+            y, h = gru_forward_train(gru, x[i:i + MAX_BATCH_PER_LAUNCH],
+                                     None if h0 is None else h0[:, i:i + MAX_BATCH_PER_LAUNCH])
+            ys.append(y)
+            hs.append(h)
+        return torch.cat(ys, dim=0), torch.cat(hs, dim=1)
+    h_init = torch.zeros((B, H), dtype=torch.float32, device=x.device) if h0 is None else h0[0].float()
+    y, status = _Gru.apply(x.contiguous(), h_init, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
+    if int(status.item()) != 0:
+        import warnings
+        warnings.warn("unet_amd.gru: the recurrence kernel gave up waiting for a workgroup that was not resident (GPU "
+                      "shared with other work?); running this call on torch's GRU")
+        return gru(x, h0)
+    h_n = y[:, -1].unsqueeze(0) if x.shape[1] > 0 else h_init.unsqueeze(0)
+    return y, h_n
+
+
 def run(gru, x, h0=None):
-    """nn.GRU's call: the persistent kernel where it applies, torch's device GRU otherwise."""
-    if supported(gru, x) and x.dtype == torch.float32:
-        return gru_forward(gru, x.contiguous(), h0)
+    """nn.GRU's call: the persistent kernels where they apply (eval: gru_forward; train: the autograd node
+    gru_forward_train), torch's device GRU otherwise."""
+    if x.dtype == torch.float32:
+        if supported(gru, x):
+            return gru_forward(gru, x.contiguous(), h0)
+        if gru.training and torch.is_grad_enabled() and _shape_supported(gru, x):
+            return gru_forward_train(gru, x, h0)
     return gru(x, h0)

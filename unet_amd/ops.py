@@ -414,6 +414,8 @@ _LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool 
 _LIBRARY.define("lstm_recurrence_train(Tensor wrec, Tensor(a!) gx, Tensor(b!) hfull, Tensor(c!) cell) -> Tensor")
 _LIBRARY.define("lstm_bptt(Tensor wrec, Tensor(a!) gates, Tensor cell, Tensor dhfull) -> Tensor")
 _LIBRARY.define("gru_recurrence(Tensor whh, Tensor bhh, Tensor gx, Tensor(a!) hfull, bool channel_major) -> Tensor")
+_LIBRARY.define("gru_recurrence_train(Tensor whh, Tensor bhh, Tensor gx, Tensor(a!) hfull, Tensor(b!) gates) -> Tensor")
+_LIBRARY.define("gru_bptt(Tensor whh, Tensor(a!) gates, Tensor hfull, Tensor dy) -> (Tensor, Tensor)")
 _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
 _LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
 _LIBRARY.define("conv2d_b16_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
@@ -696,6 +698,47 @@ def _gru_recurrence_cuda(whh, bhh, gx, hfull, channel_major):
     return sync[-1].clone()
 
 
+def _gru_sync(dev, H, kind):
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, kind, H)
+    sync = _lstm_scratch.get(key)
+    if sync is None:
+        sync = _lstm_scratch[key] = torch.empty(H // 4 + 1, dtype=torch.int32, device=dev)
+    return sync
+
+
+def _gru_recurrence_train_cuda(whh, bhh, gx, hfull, gates):
+    """gru_recurrence on step-major tensors that also fills gates [T, 4H, BP] with r, z, q = W_hn h + b_hn and n."""
+    for t, name in ((whh, "whh"), (bhh, "bhh"), (gx, "gx"), (hfull, "hfull"), (gates, "gates")):
+        _dev(t, name, "gru_recurrence_train")
+    T, G, BP = gx.shape
+    H = G // 3
+    if (G != 3 * H or tuple(whh.shape) != (G, H) or bhh.numel() != G or tuple(hfull.shape) != (T + 1, H, BP)
+            or tuple(gates.shape) != (T, 4 * H, BP)):
+        raise ValueError("unetmi::gru_recurrence_train: whh [3H,H], bhh [3H], gx [T,3H,BP], hfull [T+1,H,BP], gates [T,4H,BP] expected")
+    with torch.cuda.device(gx.device):
+        sync = _gru_sync(gx.device, H, "gru")
+        check(_lib.lib.unetmi_gru_recurrence_train(T, BP, H, _ptr(whh), _ptr(bhh), _ptr(gx), _ptr(hfull), _ptr(gates),
+                                                   _ptr(sync), _stream(gx)), "unetmi_gru_recurrence_train")
+    return sync[-1].clone()
+
+
+def _gru_bptt_cuda(whh, gates, hfull, dy):
+    """The reverse recurrence: gates [T, 4H, BP] become the pre-activation gradients in place; returns (dh0 [H, BP],
+    status word)."""
+    for t, name in ((whh, "whh"), (gates, "gates"), (hfull, "hfull"), (dy, "dy")):
+        _dev(t, name, "gru_bptt")
+    T, G, BP = gates.shape
+    H = G // 4
+    if G != 4 * H or tuple(whh.shape) != (3 * H, H) or tuple(hfull.shape) != (T + 1, H, BP) or tuple(dy.shape) != (T, H, BP):
+        raise ValueError("unetmi::gru_bptt: whh [3H,H], gates [T,4H,BP], hfull [T+1,H,BP], dy [T,H,BP] expected")
+    dh0 = torch.empty((H, BP), dtype=torch.float32, device=gates.device)
+    with torch.cuda.device(gates.device):
+        sync = _gru_sync(gates.device, H, "gru_bptt")
+        check(_lib.lib.unetmi_gru_bptt(T, BP, H, _ptr(whh), _ptr(gates), _ptr(hfull), _ptr(dy), _ptr(dh0), _ptr(sync),
+                                       _stream(gates)), "unetmi_gru_bptt")
+    return dh0, sync[H // 16].clone()
+
+
 def blocks_for(C):
     return 2 * ((C + 15) // 16)
 
@@ -837,7 +880,8 @@ for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_batch_stats", 
                    ("bn_running_update", _bn_running_update_cuda), ("bn_act_fwd", _bn_act_fwd_cuda),
                    ("bn_act_bwd", _bn_act_bwd_cuda), ("conv2d_wgrad", _conv2d_wgrad_cuda),
                    ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda),
-                   ("lstm_recurrence_train", _lstm_recurrence_train_cuda), ("lstm_bptt", _lstm_bptt_cuda), ("gru_recurrence", _gru_recurrence_cuda), ("dwconv2d_wgrad", _dwconv2d_wgrad_cuda),
+                   ("lstm_recurrence_train", _lstm_recurrence_train_cuda), ("lstm_bptt", _lstm_bptt_cuda), ("gru_recurrence", _gru_recurrence_cuda),
+                   ("gru_recurrence_train", _gru_recurrence_train_cuda), ("gru_bptt", _gru_bptt_cuda), ("dwconv2d_wgrad", _dwconv2d_wgrad_cuda),
                    ("blocked_from_nchw", _blocked_from_nchw_cuda), ("nchw_from_blocked", _nchw_from_blocked_cuda),
                    ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda), ("conv2d_b16_head_fwd", _conv2d_b16_head_fwd_cuda),
                    ("conv2d_b16_nchw_fwd", _conv2d_b16_nchw_fwd_cuda), ("blocked_from_nchw_sum", _blocked_from_nchw_sum_cuda)):
@@ -911,6 +955,16 @@ def _(whh, bhh, gx, hfull, channel_major):
     return gx.new_empty((), dtype=torch.int32)
 
 
+@torch.library.register_fake("unetmi::gru_recurrence_train")
+def _(whh, bhh, gx, hfull, gates):
+    return gx.new_empty((), dtype=torch.int32)
+
+
+@torch.library.register_fake("unetmi::gru_bptt")
+def _(whh, gates, hfull, dy):
+    return gates.new_empty((hfull.shape[1], hfull.shape[2])), gates.new_empty((), dtype=torch.int32)
+
+
 @torch.library.register_fake("unetmi::blocked_from_nchw")
 def _(x):
     N, C, H, W = x.shape
@@ -968,6 +1022,8 @@ lstm_recurrence = torch.ops.unetmi.lstm_recurrence
 lstm_recurrence_train = torch.ops.unetmi.lstm_recurrence_train
 lstm_bptt = torch.ops.unetmi.lstm_bptt
 gru_recurrence = torch.ops.unetmi.gru_recurrence
+gru_recurrence_train = torch.ops.unetmi.gru_recurrence_train
+gru_bptt = torch.ops.unetmi.gru_bptt
 dwconv2d_wgrad = torch.ops.unetmi.dwconv2d_wgrad
 blocked_from_nchw = torch.ops.unetmi.blocked_from_nchw
 nchw_from_blocked = torch.ops.unetmi.nchw_from_blocked
