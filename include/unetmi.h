@@ -152,6 +152,21 @@ int unetmi_conv2d_fwd(const UnetmiConvDesc* d,
                       const float* residual,
                       float* out, void* stream);
 
+/* Training-time form of unetmi_conv2d_fwd for a layer followed by BatchNorm2d with batch statistics
+ * (UNet_m.py:253-256 / :317-320 in train() mode: nn.Conv2d -> nn.BatchNorm2d): the convolution (bias, and the affine
+ * given by scale / shift; no activation, gate or added tensor: d->act = NONE, has_gate = has_residual = 0) whose
+ * epilogue also leaves per-tile partial sums (sum z, sum z^2) of its output, followed by one small launch that turns
+ * them into mean[K] and invstd[K] = 1 / sqrt(biased variance + eps) -- the statistics cost no pass over the tensor.
+ * The partials are added in a fixed order (lanes by a butterfly, waves and tiles in index order, in double), so the
+ * result does not depend on launch order.  ws: unetmi_conv2d_fwd_stats_workspace_bytes(d) bytes of device scratch
+ * (K x tiles x 2 doubles, every one written by the call); that function returns 0 -- and this one
+ * UNETMI_E_UNSUPPORTED -- for a layer the matrix kernels do not serve (thin layers on the streaming kernel,
+ * bfloat16 storage): run unetmi_conv2d_fwd and unetmi_bn_train_stats there. */
+size_t unetmi_conv2d_fwd_stats_workspace_bytes(const UnetmiConvDesc* d);
+int unetmi_conv2d_fwd_stats(const UnetmiConvDesc* d, const float* in0, const float* in1, const float* wpacked,
+                            const float* bias, const float* scale, const float* shift, float* out, float eps,
+                            float* mean, float* invstd, void* ws, size_t ws_bytes, void* stream);
+
 /* Depthwise (groups = C) convolution, stride 1, 'same' padding 2p = d(k-1); kernel 3x3,
  * 1x3 or 3x1.  Replaces the first conv of each ResBlock layer
  *   nn.Conv2d(C, C, (3,3), (1,1), (1,d), (1,d), groups=C)            UNet_m.py:546-548

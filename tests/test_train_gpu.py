@@ -103,6 +103,75 @@ def test_wgrad_and_input_gradient(device, case):
     assert_close(dx, x.grad, tol=2e-5, what="input gradient")
 
 
+@pytest.mark.parametrize("case", WGRAD_CASES + [
+    (0, 64, 0, 64, 257, 61, (7, 5), (2, 2), (3, 2), (0, 0)),         # several row tiles, ragged last tile
+    (1, 64, 64, 64, 33, 40, (7, 5), (2, 2), (3, 2), (1, 1)),         # two row phases x two column phases
+    (0, 128, 0, 128, 9, 70, (5, 3), (2, 1), (2, 1), (0, 0)),         # two output-channel blocks
+], ids=lambda c: "{}{}+{}-{}k{}x{}s{}x{}h{}".format("T" if c[0] else "C", c[1], c[2], c[3], c[6][0], c[6][1], c[7][0], c[7][1], c[4]))
+def test_batch_statistics_from_the_conv_epilogue(device, case):
+    """unetmi_conv2d_fwd_stats (train() mode of nn.Conv2d -> nn.BatchNorm2d, UNet_m.py:253-256): the convolution output
+    is bit-identical to unetmi_conv2d_fwd's, mean and 1/sqrt(var + eps) match float64 statistics of that output, and a
+    second call gives the same bits; layers of the streaming kernel report that they have no such epilogue."""
+    from unet_amd import _lib, ops
+    from unet_amd.train import _constant, pack_on_device
+    transposed, C0, C1, K, H, W, k, s_, p_, op = case
+    N = 3
+    geom = [K, k[0], k[1], s_[0], s_[1], p_[0], p_[1], 1, 1, op[0], op[1]]
+    flags = [int(transposed), _lib.IN_CONCAT if C1 else _lib.IN_SINGLE, _lib.ACT_NONE, 0]
+    x = _rand((N, C0 + C1, H, W), 41).to(device)
+    in0 = x[:, :C0].contiguous()
+    in1 = x[:, C0:].contiguous() if C1 else None
+    wshape = (C0 + C1, K) + tuple(k) if transposed else (K, C0 + C1) + tuple(k)
+    weight = (_rand(wshape, 42) * 0.1).to(device)
+    bias = _rand((K,), 43).to(device)
+    wp = pack_on_device(weight, geom, bool(transposed), C1)
+    ones, zeros = _constant(1.0, K, device), _constant(0.0, K, device)
+    z_ref = ops.conv2d_fwd(in0, in1, wp, bias, ones, zeros, None, None, None, geom, flags)
+    if not ops.conv2d_fwd_stats_supported(in0, in1, geom, flags):
+        name = ops.conv_kernel_name(ops.make_desc(N, C0, C1, H, W, geom, flags))
+        assert "direct" in name, name
+        with pytest.raises(_lib.UnetmiError):
+            ops.conv2d_fwd_stats(in0, in1, wp, bias, ones, zeros, 1e-5, geom, flags)
+        return
+    z, mean, invstd = ops.conv2d_fwd_stats(in0, in1, wp, bias, ones, zeros, 1e-5, geom, flags)
+    assert torch.equal(z, z_ref)
+    z64 = z_ref.double()
+    m64 = z64.mean(dim=(0, 2, 3))
+    v64 = z64.var(dim=(0, 2, 3), unbiased=False)
+    assert_close(mean.cpu(), m64.float().cpu(), tol=2e-6, what="batch mean")
+    assert_close(invstd.cpu(), torch.rsqrt(v64 + 1e-5).float().cpu(), tol=2e-6, what="1/sqrt(var + eps)")
+    z2, mean2, invstd2 = ops.conv2d_fwd_stats(in0, in1, wp, bias, ones, zeros, 1e-5, geom, flags)
+    assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2) and torch.equal(z, z2)
+    m_pass, i_pass = ops.bn_batch_stats(z_ref, 1e-5)
+    assert_close(mean.cpu(), m_pass.cpu(), tol=2e-6, what="batch mean vs the statistics pass")
+    assert_close(invstd.cpu(), i_pass.cpu(), tol=2e-6, what="invstd vs the statistics pass")
+
+
+def test_train_block_with_statistics_epilogue(device, monkeypatch):
+    """conv -> BatchNorm2d(batch statistics) -> LeakyReLU as one training node, with the statistics taken in the
+    convolution's epilogue (train.STATS_IN_EPILOGUE) and by the separate pass: same output and gradients to 1e-5."""
+    from unet_amd import _lib, train
+    conv = nn.Conv2d(64, 64, (5, 3), (2, 2), (2, 1)).to(device)
+    bn = nn.BatchNorm2d(64).to(device).train()
+    x = _rand((4, 64, 65, 48), 51).to(device)
+    g = _rand((4, 64, 33, 24), 52).to(device)
+    slope = torch.tensor([0.2], device=device)
+    results = []
+    for flag in (False, True):
+        monkeypatch.setattr(train, "STATS_IN_EPILOGUE", flag)
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        for p_ in list(conv.parameters()) + list(bn.parameters()):
+            p_.grad = None
+        xi = x.clone().requires_grad_()
+        y = train.conv_norm_act(conv, bn, _lib.ACT_LEAKY, slope, xi)
+        y.backward(g)
+        results.append([y.detach(), xi.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(),
+                        bn.running_var.clone()])
+    for a, b, what in zip(results[0], results[1], ("output", "input gradient", "weight gradient", "gamma gradient",
+                                                   "beta gradient", "running mean", "running variance")):
+        assert_close(b.cpu(), a.cpu(), tol=1e-5, what="statistics epilogue vs statistics pass: " + what)
+
+
 def test_adam_matches_torch(device):
     from unet_amd.train import adam_step
     n = 100003
@@ -390,6 +459,7 @@ def test_dsunet_train_step_matches_oracle(device):
     exact = {k: p.grad for k, p in ref64.named_parameters()}
     gmax = max(g.abs().max().item() for g in exact.values() if g is not None)
     worst = 0.0
+    report = []
     for k, p in dev.named_parameters():
         if exact[k] is None:                       # a parameter the forward does not use (in the reference as well)
             assert p.grad is None or p.grad.abs().max().item() == 0.0, k
@@ -401,7 +471,12 @@ def test_dsunet_train_step_matches_oracle(device):
         scale = max(exact[k].abs().max().item(), 1e-2 * gmax)
         err = (g - exact[k]).abs().max().item()
         worst = max(worst, err / scale)
-        assert err <= 1e-4 * scale, "grad {}: err {:.3e} of scale {:.3e}".format(k, err, scale)
+        report.append((err / scale, k))
+    if os.environ.get("UNETMI_TEST_VERBOSE") == "1":
+        for e, k in sorted(report, reverse=True)[:12]:
+            print("  {:50s} {:.2e}".format(k, e))
+    bad = [(e, k) for e, k in report if e > 1e-4]
+    assert not bad, bad[:5]
     after_ref = ref.state_dict()
     for k, v in dev.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):

@@ -30,6 +30,8 @@ EXPORTED_SYMBOLS = (
     "unetmi_conv2d_kernel_name",
     "unetmi_conv2d_pack_weights",
     "unetmi_conv2d_fwd",
+    "unetmi_conv2d_fwd_stats_workspace_bytes",
+    "unetmi_conv2d_fwd_stats",
     "unetmi_dwconv2d_fwd",
     "unetmi_dwconv2d_wgrad_workspace_bytes",
     "unetmi_dwconv2d_wgrad",
@@ -114,6 +116,10 @@ def _load():
     lib.unetmi_conv2d_pack_weights.restype = ctypes.c_int
     lib.unetmi_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 10 + [vp]
     lib.unetmi_conv2d_fwd.restype = ctypes.c_int
+    lib.unetmi_conv2d_fwd_stats_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+    lib.unetmi_conv2d_fwd_stats_workspace_bytes.restype = ctypes.c_size_t
+    lib.unetmi_conv2d_fwd_stats.argtypes = ([ctypes.POINTER(ConvDesc)] + [fp] * 7 + [ctypes.c_float, fp, fp, vp, ctypes.c_size_t, vp])
+    lib.unetmi_conv2d_fwd_stats.restype = ctypes.c_int
     ci, cf = ctypes.c_int, ctypes.c_float
     lib.unetmi_dwconv2d_fwd.argtypes = [ci] * 10 + [fp] * 5 + [ci, vp]
     lib.unetmi_dwconv2d_wgrad_workspace_bytes.argtypes = [ci] * 3

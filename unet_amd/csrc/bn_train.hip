@@ -343,6 +343,14 @@ __global__ __launch_bounds__(256) void gather_kernel(size_t n, const float* __re
     dst[i] = m >= 0 ? src[m] : 0.f;
 }
 
+// mean / invstd from per-channel partials [C][S][2] that another kernel left (the convolution's statistics epilogue)
+int launch_bn_stats_finish(const double* ws, int C, int S, long long M, float eps, float* mean, float* invstd, hipStream_t s) {
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(C), dim3(64), 0, s, ws, S, M, eps, 0.f, static_cast<float*>(nullptr),
+                       static_cast<float*>(nullptr), mean, invstd);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("bn_stats_finish launch: ") + hipGetErrorString(e));
+}
+
 }  // namespace unetmi
 
 using namespace unetmi;

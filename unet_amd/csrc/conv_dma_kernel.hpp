@@ -77,6 +77,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NG == 1 && TPG <= 4) ? 3 : 2) void c
         const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
+    const unsigned bid_all = bid;
     int a = 0;
     unsigned start = 0;
 #pragma unroll
@@ -200,6 +201,8 @@ __global__ __launch_bounds__(64 * WM * WN, (NG == 1 && TPG <= 4) ? 3 : 2) void c
         if (!ABLATE(32)) __syncthreads();      // next image landed (vmcnt 0) and everyone is done reading this one
     }
 
+    if (p.stats)                   // workgroup-uniform
+        conv_tile_stats<NG, TPG>(acc, p, s_par, smem, WM, cb, a, i0, j0, wm, wn, half, j, bid_all / p.nco_blk);
     conv_epilogue<NG, TPG>(acc, p, s_par, n, cb, a, i0, j0, wm, wn, half, j);
 }
 

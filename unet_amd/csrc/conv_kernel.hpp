@@ -31,6 +31,8 @@ struct ConvArgs {
     unsigned magic_ncols, magic_nrows;  // ceil(2^32 / d) for division of small numbers
     int xcd_remap;                      // 1: one XCD walks a contiguous run of tiles
     int bf16;                           // activations (in0, in1, residual, out) stored as bfloat16
+    double* stats;                      // training: [K][stats_S][2] per-tile (sum z, sum z^2) of the output, or null
+    int stats_S;                        // tiles per output-channel block = partials per channel
 #ifdef UNETMI_ABLATE
     int ablate;                        // developer probe only (tools/conv_probe.hip)
     unsigned long long* stamps;
@@ -271,6 +273,61 @@ __device__ __forceinline__ void group_mfma2(f32x16 (&acc0)[TPG], f32x16 (&acc1)[
     }
 }
 
+// Training: per-channel (sum z, sum z^2) of this workgroup's output tile for BatchNorm's batch statistics, taken from
+// the accumulators so that the statistics need no pass over the tensor.  z = (acc + bias) * scale + shift (the layer
+// runs without activation, gate or added tensor in this mode).  A lane adds its pixel's values over the wave's rows
+// and column phases, the 32 lanes of a half-wave (= 32 pixels of the same channels) are added by a fixed butterfly,
+// the WM waves that share channels meet in LDS (the tile buffers are free after the matrix loop) and are added in
+// wave order in double: the result does not depend on launch order.  Slot tile_lin of every channel of this
+// workgroup's block is written by exactly this workgroup.
+template <int CTRL>
+__device__ __forceinline__ float stats_dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, moved);
+}
+
+template <int NG, int TPG>
+__device__ __forceinline__ void conv_tile_stats(const f32x16 (&acc)[NG][TPG], const ConvArgs& p, const float* s_par,
+                                                float* s_red, int WM, int cb, int a, int i0, int j0, int wm, int wn,
+                                                int half, int j, unsigned tile_lin) {
+    __syncthreads();                                  // every wave has left the matrix loop: s_red may be reused
+    const int col_base = wn * 32 + 4 * half;
+    const int jj = j0 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cl = col_base + (r & 3) + 8 * (r >> 2);
+        const float b = s_par[cl], sc = s_par[p.NB + cl], sf = s_par[2 * p.NB + cl];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const bool col_ok = jj < p.w_nout[g];
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) {
+                const bool ok = col_ok && (i0 + wm * TPG + t) < p.h_nout[a];
+                const float v = ok ? (acc[g][t][r] + b) * sc + sf : 0.f;
+                s1 += v;
+                s2 += v * v;
+            }
+        }
+        s1 = stats_dpp_add<0xB1>(s1); s2 = stats_dpp_add<0xB1>(s2);        // quad_perm [1,0,3,2]
+        s1 = stats_dpp_add<0x4E>(s1); s2 = stats_dpp_add<0x4E>(s2);        // quad_perm [2,3,0,1]
+        s1 = stats_dpp_add<0x141>(s1); s2 = stats_dpp_add<0x141>(s2);      // row_half_mirror
+        s1 = stats_dpp_add<0x140>(s1); s2 = stats_dpp_add<0x140>(s2);      // row_mirror
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        if (j == 0) { s_red[(wm * p.NB + cl) * 2] = s1; s_red[(wm * p.NB + cl) * 2 + 1] = s2; }
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < p.NB && cb * p.NB + tid < p.K) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < WM; ++w) { t1 += (double)s_red[(w * p.NB + tid) * 2]; t2 += (double)s_red[(w * p.NB + tid) * 2 + 1]; }
+        double* dst = p.stats + ((size_t)(cb * p.NB + tid) * p.stats_S + tile_lin) * 2;
+        dst[0] = t1;
+        dst[1] = t2;
+    }
+    __syncthreads();                                  // s_par is read again by the epilogue; s_red is not touched after this
+}
+
 // Fused epilogue: bias, BatchNorm affine and activation (either order), gate, residual,
 // store.  Lane = one time column, register = one output channel (MFMA C/D layout).
 template <int NG, int TPG, bool BF16, int ACT>
@@ -427,6 +484,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
+    const unsigned bid_all = bid;
     int a = 0;
     unsigned start = 0;
 #pragma unroll
@@ -573,6 +631,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     }
 
     STAMP(6);                      // MFMA loops (all chunks)
+    if (p.stats)                   // workgroup-uniform
+        conv_tile_stats<NG, TPG>(acc, p, s_par, smem, WM, cb, a, i0, j0, wm, wn, half, j, bid_all / p.nco_blk);
     // ---- epilogue ---------------------------------------------------------------
     conv_epilogue<NG, TPG, BF16>(acc, p, s_par, n, cb, a, i0, j0, wm, wn, half, j);
     STAMP(7);                      // epilogue

@@ -46,13 +46,21 @@ static unsigned magic_u32(int d) {
     return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d);
 }
 
+// Partials per channel that a launch with a statistics pointer writes: one per tile of an output-channel block.
+int conv_stats_slots(const UnetmiConvDesc& d, const ConvPlan& pl) {
+    long long total = 0;
+    for (int q = 0; q < pl.h.nphase && q < kMaxPhase; ++q) total += (long long)pl.nit[q] * pl.njt * d.N;
+    return (int)total;
+}
+
 // Launches the layer.  Returns hipSuccess or the launch error.
 hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
                             const float* in0, const float* in1, const float* wpacked,
                             const float* bias, const float* scale, const float* shift,
                             const float* act_param, const float* gate, const float* residual,
-                            float* out, hipStream_t stream) {
+                            float* out, hipStream_t stream, double* stats, int stats_S) {
     ConvArgs p;
+    p.stats = stats; p.stats_S = stats_S;
     p.in0 = in0; p.in1 = in1; p.wpacked = wpacked; p.bias = bias; p.scale = scale; p.shift = shift;
     p.act_param = act_param; p.gate = gate; p.residual = residual; p.out = out;
     p.N = d.N; p.C0 = d.C0; p.C1 = d.C1; p.Ctot = pl.Ctot; p.H = d.H; p.W = d.W; p.K = d.K;

@@ -12,7 +12,9 @@ hipError_t launch_conv_mfma(const UnetmiConvDesc& d, const ConvPlan& pl,
                             const float* in0, const float* in1, const float* wpacked,
                             const float* bias, const float* scale, const float* shift,
                             const float* act_param, const float* gate, const float* residual,
-                            float* out, hipStream_t stream);
+                            float* out, hipStream_t stream, double* stats, int stats_S);
+int conv_stats_slots(const UnetmiConvDesc& d, const ConvPlan& pl);
+int launch_bn_stats_finish(const double* ws, int C, int S, long long M, float eps, float* mean, float* invstd, hipStream_t s);
 
 hipError_t launch_direct_conv(const UnetmiConvDesc& d, const ConvPlan& pl,
                               const float* in0, const float* in1, const float* wpacked,
@@ -145,10 +147,50 @@ int unetmi_conv2d_fwd(const UnetmiConvDesc* d, const float* in0, const float* in
     if (!pl.direct && pl.NG == 2 && needs_two_loads(*d, pl))
         return fail(UNETMI_E_UNSUPPORTED,
                     "summed two-source input on a time-stride-2 transposed conv: add the inputs first");
-    const hipError_t e = (pl.direct ? launch_direct_conv : launch_conv_mfma)(*d, pl, in0, in1, wpacked, bias, scale, shift, act_param,
-                                          gate, residual, out, static_cast<hipStream_t>(stream));
+    const hipError_t e = pl.direct ? launch_direct_conv(*d, pl, in0, in1, wpacked, bias, scale, shift, act_param, gate, residual, out,
+                                                        static_cast<hipStream_t>(stream))
+                                   : launch_conv_mfma(*d, pl, in0, in1, wpacked, bias, scale, shift, act_param, gate, residual, out,
+                                                      static_cast<hipStream_t>(stream), nullptr, 0);
     if (e != hipSuccess) return fail(UNETMI_E_HIP, std::string("conv launch: ") + hipGetErrorString(e));
     return UNETMI_OK;
+}
+
+size_t unetmi_conv2d_fwd_stats_workspace_bytes(const UnetmiConvDesc* d) {
+    if (!d) { fail(UNETMI_E_BAD_ARG, "null descriptor"); return 0; }
+    ConvPlan pl;
+    std::string err;
+    if (!make_plan(*d, &pl, &err)) { fail(UNETMI_E_BAD_DESC, err); return 0; }
+    if (pl.direct || d->reserved[0] != UNETMI_DTYPE_F32 || d->act != UNETMI_ACT_NONE || d->has_gate || d->has_residual) {
+        fail(UNETMI_E_UNSUPPORTED, "conv2d_fwd_stats: an fp32 layer of the matrix kernels without activation, gate or added tensor");
+        return 0;
+    }
+    return (size_t)d->K * (size_t)conv_stats_slots(*d, pl) * 2 * sizeof(double);
+}
+
+int unetmi_conv2d_fwd_stats(const UnetmiConvDesc* d, const float* in0, const float* in1, const float* wpacked,
+                            const float* bias, const float* scale, const float* shift, float* out, float eps,
+                            float* mean, float* invstd, void* ws, size_t ws_bytes, void* stream) {
+    if (!d) return fail(UNETMI_E_BAD_ARG, "null descriptor");
+    const size_t need = unetmi_conv2d_fwd_stats_workspace_bytes(d);
+    if (need == 0) return d->N == 0 ? fail(UNETMI_E_BAD_DESC, "conv2d_fwd_stats: empty batch") : UNETMI_E_UNSUPPORTED;
+    ConvPlan pl;
+    std::string err;
+    if (!make_plan(*d, &pl, &err)) return fail(UNETMI_E_BAD_DESC, err);
+    if (!in0 || !wpacked || !bias || !scale || !shift || !out || !mean || !invstd || !ws)
+        return fail(UNETMI_E_BAD_ARG, "conv2d_fwd_stats: null pointer");
+    if (d->in_mode != UNETMI_IN_SINGLE && !in1) return fail(UNETMI_E_BAD_ARG, "in_mode needs in1");
+    if (ws_bytes < need) return fail(UNETMI_E_BAD_ARG, "conv2d_fwd_stats: workspace too small");
+    if (pl.lds_bytes_dma > 80 * 1024) return fail(UNETMI_E_UNSUPPORTED, "LDS images exceed 80 KB");
+    if (d->reserved[1] < 0 || d->reserved[1] > 6 || d->reserved[1] == 3)
+        return fail(UNETMI_E_BAD_DESC, "reserved[1] (row tiles per wave) must be 0, 1, 2, 4, 5 or 6");
+    if (pl.NG == 2 && needs_two_loads(*d, pl))
+        return fail(UNETMI_E_UNSUPPORTED, "summed two-source input on a time-stride-2 transposed conv: add the inputs first");
+    const int S = conv_stats_slots(*d, pl);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const hipError_t e = launch_conv_mfma(*d, pl, in0, in1, wpacked, bias, scale, shift, nullptr, nullptr, nullptr, out, s,
+                                          static_cast<double*>(ws), S);
+    if (e != hipSuccess) return fail(UNETMI_E_HIP, std::string("conv launch: ") + hipGetErrorString(e));
+    return launch_bn_stats_finish(static_cast<const double*>(ws), d->K, S, (long long)d->N * d->OH * d->OW, eps, mean, invstd, s);
 }
 
 }  // extern "C"

@@ -159,6 +159,65 @@ def _conv2d_fwd_cuda(in0, in1, wpacked, bias, scale, shift, act_param, gate, res
 
 _LIBRARY.impl("conv2d_fwd", _conv2d_fwd_cuda, "CUDA")
 
+_LIBRARY.define("conv2d_fwd_stats(Tensor in0, Tensor? in1, Tensor wpacked, Tensor bias, Tensor scale, Tensor shift, float eps, "
+                "int[] geom, int[] flags) -> (Tensor, Tensor, Tensor)")
+
+
+def conv2d_fwd_stats_supported(in0, in1, geom, flags):
+    """The layer's kernel has the statistics epilogue (unetmi_conv2d_fwd_stats_workspace_bytes != 0)."""
+    if in0.dtype != torch.float32:
+        return False
+    d = make_desc(in0.shape[0], in0.shape[1], 0 if in1 is None else in1.shape[1], in0.shape[2], in0.shape[3], geom, flags,
+                  0, 0, 0, dtype_code(in0))
+    return in0.shape[0] > 0 and _lib.lib.unetmi_conv2d_fwd_stats_workspace_bytes(ctypes.byref(d)) != 0
+
+
+def _conv2d_fwd_stats_cuda(in0, in1, wpacked, bias, scale, shift, eps, geom, flags):
+    """(z, mean, invstd): the convolution (no activation) and the batch statistics of its output, the per-channel
+    sums taken in the convolution's epilogue.  flags = [transposed, in_mode, ACT_NONE, 0]."""
+    _need(in0, "in0")
+    N, C0, H, W = in0.shape
+    C1 = 0
+    if in1 is not None:
+        _need(in1, "in1")
+        if in1.shape[0] != N or tuple(in1.shape[2:]) != (H, W):
+            raise ValueError("unetmi::conv2d_fwd_stats: in1 {} does not match in0 {}".format(tuple(in1.shape), tuple(in0.shape)))
+        C1 = in1.shape[1]
+    K = geom[0]
+    d = make_desc(N, C0, C1, H, W, geom, flags, 0, 0, 0, dtype_code(in0))
+    for t, name in ((bias, "bias"), (scale, "scale"), (shift, "shift")):
+        _need(t, name, (K,))
+    _need(wpacked, "wpacked")
+    expect = _lib.lib.unetmi_conv2d_packed_weight_bytes(ctypes.byref(d))
+    if expect == 0:
+        raise _lib.UnetmiError("unetmi::conv2d_fwd_stats: " + _lib.last_error())
+    if wpacked.numel() * 4 != expect:
+        raise ValueError("unetmi::conv2d_fwd_stats: packed weight image has {} bytes, expected {}".format(wpacked.numel() * 4, expect))
+    need = _lib.lib.unetmi_conv2d_fwd_stats_workspace_bytes(ctypes.byref(d))
+    if need == 0:
+        raise _lib.UnetmiError("unetmi::conv2d_fwd_stats: " + _lib.last_error(), _lib.E_UNSUPPORTED)
+    out = torch.empty((N, K, d.OH, d.OW), dtype=torch.float32, device=in0.device)
+    mean = torch.empty((K,), dtype=torch.float32, device=in0.device)
+    invstd = torch.empty((K,), dtype=torch.float32, device=in0.device)
+    ws = workspace(in0.device, need)
+    with torch.cuda.device(in0.device):
+        check(_lib.lib.unetmi_conv2d_fwd_stats(ctypes.byref(d), _ptr(in0), _ptr(in1), _ptr(wpacked), _ptr(bias), _ptr(scale),
+                                               _ptr(shift), _ptr(out), float(eps), _ptr(mean), _ptr(invstd), _ptr(ws), need,
+                                               torch.cuda.current_stream().cuda_stream), "unetmi_conv2d_fwd_stats")
+    return out, mean, invstd
+
+
+_LIBRARY.impl("conv2d_fwd_stats", _conv2d_fwd_stats_cuda, "CUDA")
+
+
+@torch.library.register_fake("unetmi::conv2d_fwd_stats")
+def _(in0, in1, wpacked, bias, scale, shift, eps, geom, flags):
+    z = _conv2d_fwd_fake(in0, in1, wpacked, bias, scale, shift, None, None, None, geom, flags)
+    return z, z.new_empty((geom[0],)), z.new_empty((geom[0],))
+
+
+conv2d_fwd_stats = torch.ops.unetmi.conv2d_fwd_stats
+
 
 @torch.library.register_fake("unetmi::conv2d_fwd")
 def _conv2d_fwd_fake(in0, in1, wpacked, bias, scale, shift, act_param, gate, residual, geom, flags):

@@ -110,21 +110,40 @@ def pack_on_device(weight, geom, transposed, c1=0):
     return _ops.gather_f32(weight.detach().contiguous(), idx)        # one launch; padding positions are -1 in the map
 
 
-def _plain_conv(x, x2, weight, bias, geom, transposed):
-    """conv / transposed conv + bias, nothing else."""
+# Batch statistics from the convolution's epilogue (unetmi_conv2d_fwd_stats) where the layer's kernel has one, instead
+# of the separate statistics pass (unetmi_bn_train_stats).  Off by default: at the benchmark's batch of 8 the pass reads
+# a tensor the convolution has just left in the last-level cache, and the step time is the same either way
+# (19.62 ms with the epilogue, 19.58 without), while the epilogue's fp32 tile sums are slightly less exact than the
+# pass's double sums.  UNETMI_STATS_EPILOGUE=1 (or setting this flag) turns it on.
+STATS_IN_EPILOGUE = os.environ.get("UNETMI_STATS_EPILOGUE", "0") == "1"
+
+
+def _plain_conv(x, x2, weight, bias, geom, transposed, stats_eps=None):
+    """conv / transposed conv + bias, nothing else.  With ``stats_eps``: (z, mean, invstd), the batch statistics of z
+    taken in the convolution's epilogue where the layer's kernel has that epilogue, by a pass over z otherwise."""
     K = geom[0]
     wpacked = pack_on_device(weight, geom, transposed, x2.shape[1] if x2 is not None else 0)
     ones, zeros = _constant(1.0, K, x.device), _constant(0.0, K, x.device)
     b = bias.detach() if bias is not None else zeros
     mode = _lib.IN_SINGLE if x2 is None else _lib.IN_CONCAT
     flags = [int(transposed), mode, _lib.ACT_NONE, 0]
+    if stats_eps is not None and STATS_IN_EPILOGUE and _ops.conv2d_fwd_stats_supported(x, x2, geom, flags):
+        try:
+            return _ops.conv2d_fwd_stats(x, x2, wpacked, b, ones, zeros, stats_eps, geom, flags)
+        except _lib.UnetmiError as e:
+            if e.code != _lib.E_UNSUPPORTED:
+                raise
     try:
-        return conv2d_fwd(x, x2, wpacked, b, ones, zeros, None, None, None, geom, flags)
+        z = conv2d_fwd(x, x2, wpacked, b, ones, zeros, None, None, None, geom, flags)
     except _lib.UnetmiError as e:
         if e.code != _lib.E_UNSUPPORTED or x2 is None:
             raise
-    return conv2d_fwd(torch.cat([x, x2], dim=1), None, pack_on_device(weight, geom, transposed), b, ones, zeros,
-                      None, None, None, geom, [int(transposed), _lib.IN_SINGLE, _lib.ACT_NONE, 0])
+        z = conv2d_fwd(torch.cat([x, x2], dim=1), None, pack_on_device(weight, geom, transposed), b, ones, zeros,
+                       None, None, None, geom, [int(transposed), _lib.IN_SINGLE, _lib.ACT_NONE, 0])
+    if stats_eps is None:
+        return z
+    mean, invstd = _ops.bn_batch_stats(z, stats_eps)
+    return z, mean, invstd
 
 
 def _input_gradient(dz, weight, geom, transposed, in_hw):
@@ -161,10 +180,13 @@ _ops._LIBRARY.define(
 
 def _conv_norm_act_cuda(x, skip, weight, bias, gamma, beta, running_mean, running_var, geom, transposed, norm_mode,
                         eps, act, act_param):
-    z = _plain_conv(x, skip, weight, bias, geom, transposed)
+    if norm_mode == 1:
+        z, mean, invstd = _plain_conv(x, skip, weight, bias, geom, transposed, stats_eps=eps)
+    else:
+        z = _plain_conv(x, skip, weight, bias, geom, transposed)
     K, dev = geom[0], z.device
     if norm_mode == 1:
-        mean, invstd = _ops.bn_batch_stats(z, eps)
+        pass
     elif norm_mode == 2:
         mean = running_mean.detach()
         invstd = torch.rsqrt(running_var.detach() + eps)
