@@ -661,12 +661,15 @@ def test_projected_lstm_gradients(device, B, T, layers):
     xd = x.to(device).requires_grad_()
     y = L.lstm_forward_train(dev_lstm, xd)
     assert_close(y.detach().cpu(), y64.detach().float(), tol=2e-5, what="projected LSTM output")
-    y.backward(g.to(device))
+    y.backward(g.to(device), retain_graph=True)
     assert_close(xd.grad.cpu(), x64.grad.float(), tol=2e-5, what="projected LSTM input gradient")
     exact = dict(ref.named_parameters())
     for k, p in dev_lstm.named_parameters():
         assert p.grad is not None, k
         assert_close(p.grad.cpu(), exact[k].grad.float(), tol=2e-5, what="projected LSTM gradient of " + k)
+    # a second backward pass through the same graph would read gates that are gradients by now: refused, not wrong
+    with pytest.raises(RuntimeError, match="retain_graph"):
+        y.backward(g.to(device))
     # a second step on the same module: nothing from the first call is kept
     for p in dev_lstm.parameters():
         p.grad = None

@@ -113,6 +113,10 @@ class _Gru(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dstatus):
         B, T, C, H, BP = ctx.dims
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("unet_amd.gru: this node's saved gates were turned into gradients by an earlier backward "
+                               "pass; a second pass through the same graph (retain_graph) is not supported")
+        ctx.consumed = True
         w_ih, w_hh, seq, hfull, gates = ctx.saved_tensors
         dev = dy.device
         with torch.cuda.device(dev):

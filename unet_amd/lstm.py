@@ -218,6 +218,10 @@ class _ProjectedLstm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dstatus):
         B, T, BP, L = ctx.dims
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("unet_amd.lstm: this node's saved gates were turned into gradients by an earlier backward "
+                               "pass; a second pass through the same graph (retain_graph) is not supported")
+        ctx.consumed = True
         params, saved = ctx.saved_tensors[:5 * L], ctx.saved_tensors[5 * L:]
         dev = dout.device
         grads = [None] * (5 * L)
