@@ -262,7 +262,8 @@ int unetmi_gru_bptt(int T, int BP, int H, const float* whh, float* gates, const 
 /* The same recurrence with the batch split over the chip's 8 XCDs (4 batch columns each, BP <= 32): every XCD runs
  * an independent recurrence for its columns, the state exchange stays inside that XCD's L2 and there is no
  * device-wide barrier (about 2 us per step instead of 6-7).  Arguments and results as unetmi_lstm_recurrence.
- * ws: unetmi_lstm_recurrence_xcd_workspace_bytes() bytes of device scratch (cleared by the call).  Needs a
+ * ws: unetmi_lstm_recurrence_xcd_workspace_bytes() bytes of device scratch (cleared by the call).  H = 640 (one
+ * workgroup on each of the 256 compute units) or 300 (padded to 320 inside: 16 workgroups per XCD).  Needs a
  * device of 8 XCDs x 32 compute units with one workgroup resident per compute unit (UNETMI_E_UNSUPPORTED
  * otherwise: use unetmi_lstm_recurrence).  A workgroup finds its XCD from the hardware, not from its index.
  * Status: ((uint32_t*)ws)[8] is non-zero after an aborted run (a workgroup was not resident, e.g. the GPU is
@@ -276,7 +277,8 @@ int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wrec, const fl
                                int channel_major, void* ws, size_t ws_bytes, void* stream);
 
 /* The projected LSTM under autograd (train() mode of ResUNet: nn.LSTM(384, 640, 3, proj_size=384), ResUNet.py:139,
- * :186-197, whose backward the reference leaves to torch autograd).  Channel-major layouts only, H = 640, BP <= 32,
+ * :186-197, whose backward the reference leaves to torch autograd; also the hidden-size-300 LSTMs of ResUNet.py:335 and
+ * UNet_m.py:587-610).  Channel-major layouts only, H = 640 or 300, BP <= 32,
  * same device requirements, workspace rules and status word as unetmi_lstm_recurrence_xcd.
  *
  * unetmi_lstm_recurrence_xcd_train: the forward recurrence that also keeps what backpropagation through time needs.

@@ -795,8 +795,9 @@ def test_instance_norm_blocks_one_launch(device, case, dtype):
 @pytest.mark.parametrize("B,T", [(2, 33), (32, 12), (70, 5)])
 def test_projected_lstm_hidden_300(device, shape, B, T):
     """The projected LSTMs of ResUNetOnFreq (ResUNet.py:335: LSTM(192, 300, 3, proj 192)) and of LSTMBlock
-    (UNet_m.py:587-610: LSTM(210, 300, 3, proj 210)) on the device-wide-barrier recurrence kernel -- hidden size 300
-    is padded to 304 rows per state slot -- against torch's CPU LSTM."""
+    (UNet_m.py:587-610: LSTM(210, 300, 3, proj 210)) against torch's CPU LSTM, on both recurrence kernels: the
+    XCD-local one (hidden size 300 padded to 320 = 16 workgroups of 20 units per XCD) and the device-wide-barrier one
+    (a state slot padded to 304 rows)."""
     import copy
     import unet_amd
     from unet_amd.lstm import lstm_forward, supported
@@ -810,9 +811,10 @@ def test_projected_lstm_hidden_300(device, shape, B, T):
     x = normal("lstm300/x", (B, T, n_in), seed=73)
     with torch.no_grad():
         want = ref(x)[0]
-    got = lstm_forward(copy.deepcopy(ref).to(device), x.to(device), {})
-    assert not torch.isnan(got).any(), "the recurrence kernel aborted"
-    assert_close(got, want, tol=2e-5, what="projected LSTM, hidden 300")
+    for force_grid in (False, True):
+        got = lstm_forward(copy.deepcopy(ref).to(device), x.to(device), {}, _force_grid=force_grid)
+        assert not torch.isnan(got).any(), "the recurrence kernel aborted"
+        assert_close(got, want, tol=2e-5, what="projected LSTM, hidden 300, " + ("barrier kernel" if force_grid else "XCD kernel"))
 
 
 @pytest.mark.parametrize("n_in,hidden", [(128, 128), (256, 512), (256, 256)])

@@ -639,20 +639,23 @@ def test_resblock_train_step_matches_oracle(device, channels):
                                "ResBlock({}) train step".format(channels))
 
 
-@pytest.mark.parametrize("B,T,layers", [(5, 12, 3), (32, 37, 2), (37, 9, 1), (4, 501, 3)])
-def test_projected_lstm_gradients(device, B, T, layers):
-    """The projected LSTM as an autograd node (ResUNet.py:139: nn.LSTM(384, 640, 3, proj_size=384, batch_first)):
+@pytest.mark.parametrize("B,T,layers,dims", [(5, 12, 3, (384, 640)), (32, 37, 2, (384, 640)), (37, 9, 1, (384, 640)),
+                                             (4, 501, 3, (384, 640)), (6, 21, 3, (192, 300)), (32, 14, 2, (210, 300))])
+def test_projected_lstm_gradients(device, B, T, layers, dims):
+    """The projected LSTM as an autograd node (ResUNet.py:139: nn.LSTM(384, 640, 3, proj_size=384, batch_first);
+    ResUNet.py:335: LSTM(192, 300, 3, proj_size=192); UNet_m.py:587-610: LSTM(210, 300, 3, proj_size=210)):
     forward recurrence saving gates and cell states, backpropagation through time as one persistent launch per layer,
     weight gradients as time-batched products.  Output, input gradient and all 5 parameter gradients per layer
     against float64 autograd of torch's CPU LSTM; B=37 runs as two groups of sequences, T=501 is the benchmark's
     sequence length."""
     from unet_amd import lstm as L
     torch.manual_seed(7)
-    ref = nn.LSTM(384, 640, layers, batch_first=True, proj_size=384)
+    C, H = dims
+    ref = nn.LSTM(C, H, layers, batch_first=True, proj_size=C)
     dev_lstm = copy.deepcopy(ref).to(device)
     ref = ref.double()
-    x = _rand((B, T, 384), 21)
-    g = _rand((B, T, 384), 22)
+    x = _rand((B, T, C), 21)
+    g = _rand((B, T, C), 22)
     if not L.trainable_on_device(dev_lstm, x.to(device)):
         pytest.skip("the XCD-local recurrence kernels need a device of 8 XCDs x 32 compute units")
     x64 = x.double().requires_grad_()

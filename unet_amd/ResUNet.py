@@ -296,8 +296,8 @@ class ResUNetOnFreq(nn.Module):
 
 
 class LSTMBlock(nn.Module):
-    """[B,C,F',T] -> [B,T,C*F'] -> projected LSTM -> back (UNet_m.py:587-610): the recurrence kernel for hidden
-    sizes 300 and 640, torch's device LSTM otherwise."""
+    """[B,C,F',T] -> [B,T,C*F'] -> projected LSTM -> back (UNet_m.py:587-610): the recurrence kernels for hidden
+    sizes 300 and 640 (eval, and train() without dropout between the layers), torch's device LSTM otherwise."""
 
     def __init__(self, n_dim, n_hidden, n_layer=3, proj_size=None, dropout=0.2):
         super().__init__()
@@ -309,11 +309,13 @@ class LSTMBlock(nn.Module):
     def forward(self, x):
         require_device_tensor(x, "LSTMBlock")
         B, C, F, T = x.shape
-        seq = x.reshape(B, C * F, T).permute(0, 2, 1)
+        seq = x.reshape(B, C * F, T).permute(0, 2, 1).float().contiguous()
         if lstm_supported(self.rnn) and not self.training:   # hidden size 300 / 640: one persistent recurrence launch per layer
-            y = lstm_forward(self.rnn, seq.float().contiguous(), self._lstm_cache).to(x.dtype)
+            y = lstm_forward(self.rnn, seq, self._lstm_cache).to(x.dtype)
+        elif self.training and torch.is_grad_enabled() and trainable_on_device(self.rnn, seq):
+            y = lstm_forward_train(self.rnn, seq).to(x.dtype)   # the same kernels as an autograd node
         else:
-            y = self.rnn(seq.float())[0].to(x.dtype)
+            y = self.rnn(seq)[0].to(x.dtype)
         return y.permute(0, 2, 1).reshape(B, C, F, T).contiguous()
 
 

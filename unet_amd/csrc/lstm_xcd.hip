@@ -38,11 +38,13 @@ int api_fail(int code, const std::string& msg);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kXH = 640;                 // hidden size
-constexpr int kXcds = 8, kXWg = 32;      // XCDs, workgroups (compute units) per XCD
-constexpr int kXU = kXH / kXWg;          // hidden units per workgroup (20)
+// The kernels are instantiated per PADDED hidden size HP: 640 (ResUNet's bottleneck: 32 workgroups per XCD) and 320
+// (hidden size 300 of ResUNetOnFreq / LSTMBlock, ResUNet.py:335, UNet_m.py:587-610: 16 workgroups per XCD).  Units
+// H..HP-1 meet zero weights, publish zeros and touch no caller tensor.
+constexpr int kXHMax = 640;              // largest padded hidden size (workspace sizing)
+constexpr int kXcds = 8;                 // XCDs
+constexpr int kXU = 20;                  // hidden units per workgroup: HP / (workgroups per XCD)
 constexpr int kXSets = kXU / 4;          // MFMA accumulator sets: 4 units each (5)
-constexpr int kXKg = kXH / 4 / 4;        // k-groups per wave: 160 columns / 4 per instruction (40)
 constexpr int kXCols = 4;                // batch columns per XCD
 constexpr unsigned kXSpinLimit = 1u << 20;
 
@@ -52,7 +54,7 @@ struct LstmXcdArgs {
     float* hfull;               // step-major [T+1][H][BP], or channel-major [H][T+1][BP]
     unsigned* ctl;              // [8] tickets, [8] abort word (+ padding to 64 words)
     unsigned long long* hx;     // [8 XCDs][2 parities][H][4] granules {float value, unsigned step}
-    int T, BP;
+    int T, BP, H;               // H: the real hidden size (rows of wrec / gx are g*H + u)
     long long gx_step, gx_row, gx_first;      // element strides of gx per step / per gate row, offset of step 0
     long long h_step, h_row;                  // element strides of hfull per step slot / per hidden unit
     float* gates;               // training form: the activated gates i, f, g, o of step t, laid out (and strided) as gx;
@@ -69,8 +71,11 @@ __device__ __forceinline__ float dpp_add(float v) {     // v + (v moved by the D
 
 // SAVE: also keep what backpropagation through time needs -- the four activated gates of every step (written over
 // the step's input contribution: a.gates may be a.gx) and the cell state.
-template <bool SAVE>
+template <bool SAVE, int kXH>
 __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
+    constexpr int kXWg = kXH / kXU;          // workgroups (compute units) used per XCD
+    constexpr int kXKg = kXH / 4 / 4;        // k-groups per wave: HP/4 columns / 4 per instruction
+    constexpr int kXLd = kXH / 64;           // state granules a lane reads per step
     __shared__ float s_h[4][kXH];                          // per wave: its quarter of the state, [k][col]
     __shared__ float s_part[2][4][kXSets][4][16];          // [parity][wave][set][gate][unit-in-set * 4 + col]
     __shared__ int s_slot;
@@ -93,14 +98,15 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
     float A[kXSets][kXKg];
 #pragma unroll
     for (int s = 0; s < kXSets; ++s) {
-        const float* row = a.wrec + (size_t)(r * kXH + u_base + 4 * s + ui) * kXH + 160 * wave + ki;
+        const int u = u_base + 4 * s + ui, k0 = kXH / 4 * wave + ki;
+        const float* row = a.wrec + (size_t)(r * a.H + u) * a.H + k0;
 #pragma unroll
-        for (int kg = 0; kg < kXKg; ++kg) A[s][kg] = row[4 * kg];
+        for (int kg = 0; kg < kXKg; ++kg) A[s][kg] = (u < a.H && k0 + 4 * kg < a.H) ? row[4 * kg] : 0.f;
     }
-    // gate thread: cell (unit ul, column cj) of this workgroup
+    // gate thread: cell (unit ul, column cj) of this workgroup; a padding unit (>= H) only publishes zeros
     const bool gate_thread = tid < kXU * kXCols;
     const int ul = tid >> 2, cj = tid & 3;
-    const bool col_live = col0 + cj < a.BP;
+    const bool col_live = col0 + cj < a.BP && u_base + ul < a.H;
     float c = 0.f;
 
     unsigned long long* hx = a.hx + (size_t)xcd * 2 * kXH * kXCols;
@@ -113,16 +119,16 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
         if (gate_thread && col_live) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                gxv[g] = a.gx[a.gx_first + t * a.gx_step + (g * kXH + u_base + ul) * a.gx_row + col0 + cj];
+                gxv[g] = a.gx[a.gx_first + t * a.gx_step + (g * a.H + u_base + ul) * a.gx_row + col0 + cj];
         }
-        // ---- this wave's quarter of h_t: granules (160*wave + e/4, e%4), e = lane + 64*i, until all read step t ----
-        const unsigned long long* src = hx + (size_t)(t & 1) * kXH * kXCols + (size_t)wave * 160 * kXCols;
+        // ---- this wave's quarter of h_t: granules (HP/4*wave + e/4, e%4), e = lane + 64*i, until all read step t ----
+        const unsigned long long* src = hx + (size_t)(t & 1) * kXH * kXCols + (size_t)wave * (kXH / 4) * kXCols;
         unsigned spins = 0;
         for (;;) {
             bool ok = true;
-            float v[10];
+            float v[kXLd];
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
+            for (int i = 0; i < kXLd; ++i) {
                 // device-scope loads: they never hit this compute unit's vector cache (a line cached before the
                 // producers' stores would otherwise be hit again and again) and are served by the XCD's L2, where
                 // those stores land.  Measured alternatives: invalidating the vector cache before plain loads is 3x
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
             }
             if (__all(ok)) {
 #pragma unroll
-                for (int i = 0; i < 10; ++i) sh[lane + 64 * i] = v[i];
+                for (int i = 0; i < kXLd; ++i) sh[lane + 64 * i] = v[i];
                 break;
             }
             if ((++spins & 63u) == 0u) {
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
         for (int s = 0; s < kXSets; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
         // The state operands are read a group of 8 k-blocks ahead into a second register set: one read waited for
         // in front of each 10 MFMAs (80 cycles) put ~19 LDS round trips on the critical path of every time step.
-        constexpr int kGrp = 8;
+        constexpr int kGrp = kXKg % 8 == 0 ? 8 : 4;
         static_assert(kXKg % kGrp == 0, "k-blocks come in whole groups");
         float bv[2][kGrp];
 #pragma unroll
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
                 const float gv[4] = {ig, fg, gg, og};
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    a.gates[a.gx_first + t * a.gx_step + (g * kXH + u_base + ul) * a.gx_row + col0 + cj] = gv[g];
+                    a.gates[a.gx_first + t * a.gx_step + (g * a.H + u_base + ul) * a.gx_row + col0 + cj] = gv[g];
                 a.cell[(t + 1) * a.h_step + (u_base + ul) * a.h_row + col0 + cj] = c;
             }
         }
@@ -238,15 +244,16 @@ struct LstmXcdBwdArgs {
     const float* cell;          // [H][T+1][BP]: c_t at slot t+1, slot 0 = 0
     const float* dhfull;        // [H][T+1][BP]: gradient reaching m_t through the projection, at slot t+1
     unsigned* ctl;              // [8] tickets, [8] abort word (+ padding to 64 words)
-    unsigned long long* gxch;   // [8 XCDs][2 parities][4H][4] granules {float value, unsigned step}
-    int T, BP;
+    unsigned long long* gxch;   // [8 XCDs][2 parities][4 HP][4] granules {float value, unsigned step}
+    int T, BP, H;
 };
 
-constexpr int kXG = 4 * kXH;             // exchanged rows per step (2560)
-constexpr int kXBKg = kXH / 16;          // k-groups per wave: 640 rows / 16 per instruction (40)
-constexpr int kXBLd = kXH * kXCols / 64; // granules a lane reads per step (40)
-
+template <int kXH>
 __global__ __launch_bounds__(256, 1) void lstm_xcd_bwd_kernel(const LstmXcdBwdArgs a) {
+    constexpr int kXWg = kXH / kXU;          // workgroups used per XCD
+    constexpr int kXG = 4 * kXH;             // exchanged rows per step
+    constexpr int kXBKg = kXH / 16;          // k-groups per wave: HP rows / 16 per instruction
+    constexpr int kXBLd = kXH * kXCols / 64; // granules a lane reads per step
     __shared__ float s_g[4][kXH * kXCols];                 // per wave: its gate's rows of G, [k][col]
     __shared__ float s_part[2][4][4][kXSets][4][4];        // [parity][wave][row of 16 lanes][set][unit][col]
     __shared__ int s_slot;
@@ -268,13 +275,14 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_bwd_kernel(const LstmXcdBwdAr
     float A[kXSets][kXBKg];
 #pragma unroll
     for (int s = 0; s < kXSets; ++s) {
-        const float* colp = a.wrec + (size_t)(kXH * wave + b) * kXH + u_base + 4 * s + r;
+        const int u = u_base + 4 * s + r;
+        const float* colp = a.wrec + (size_t)(a.H * wave + b) * a.H + u;
 #pragma unroll
-        for (int kg = 0; kg < kXBKg; ++kg) A[s][kg] = colp[(size_t)16 * kg * kXH];
+        for (int kg = 0; kg < kXBKg; ++kg) A[s][kg] = (u < a.H && b + 16 * kg < a.H) ? colp[(size_t)16 * kg * a.H] : 0.f;
     }
     const bool gate_thread = tid < kXU * kXCols;
     const int ul = tid >> 2, cj = tid & 3;
-    const bool col_live = col0 + cj < a.BP;
+    const bool col_live = col0 + cj < a.BP && u_base + ul < a.H;
     const long long row = (long long)(a.T + 1) * a.BP;
     float dc_carry = 0.f;                                  // dc_{t+1} * f_{t+1}
 
@@ -289,12 +297,12 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_bwd_kernel(const LstmXcdBwdAr
         if (gate_thread && col_live) {
             const long long at = (long long)(t + 1) * a.BP + col0 + cj;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gv[g] = a.gates[(g * kXH + u_base + ul) * row + at];
+            for (int g = 0; g < 4; ++g) gv[g] = a.gates[(g * a.H + u_base + ul) * row + at];
             c_t = a.cell[(u_base + ul) * row + at];
             c_prev = a.cell[(u_base + ul) * row + at - a.BP];
             dm = a.dhfull[(u_base + ul) * row + at];
         }
-        // ---- this wave's gate of G_{t+1}: granules (640*wave + e/4, e%4), e = lane + 64*i, until all carry tag s ----
+        // ---- this wave's gate of G_{t+1}: granules (HP*wave + e/4, e%4), e = lane + 64*i, until all carry tag s ----
         const unsigned long long* src = gx + (size_t)(s & 1) * kXG * kXCols + (size_t)wave * kXH * kXCols;
         unsigned spins = 0;
         for (;;) {
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_bwd_kernel(const LstmXcdBwdAr
         f32x4 acc[kXSets];
 #pragma unroll
         for (int q = 0; q < kXSets; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int kGrp = 8;
+        constexpr int kGrp = kXBKg % 8 == 0 ? 8 : 4;
         static_assert(kXBKg % kGrp == 0, "k-groups come in whole groups");
         float bv[2][kGrp];
 #pragma unroll
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_bwd_kernel(const LstmXcdBwdAr
                     (unsigned long long)__builtin_bit_cast(unsigned, val) | ((unsigned long long)(unsigned)(s + 1) << 32);
                 __hip_atomic_store(&gx[(size_t)((s + 1) & 1) * kXG * kXCols + (size_t)(g * kXH + u_base + ul) * kXCols + cj],
                                    granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (col_live) a.gates[(g * kXH + u_base + ul) * row + (long long)(t + 1) * a.BP + col0 + cj] = val;
+                if (col_live) a.gates[(g * a.H + u_base + ul) * row + (long long)(t + 1) * a.BP + col0 + cj] = val;
             }
         }
     }
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_bwd_kernel(const LstmXcdBwdAr
         for (int ss = s; ss < a.T; ++ss)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                a.gates[(g * kXH + u_base + ul) * row + (long long)(a.T - ss) * a.BP + col0 + cj] = __builtin_nanf("");
+                a.gates[(g * a.H + u_base + ul) * row + (long long)(a.T - ss) * a.BP + col0 + cj] = __builtin_nanf("");
 }
 
 }  // namespace unetmi
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_bwd_kernel(const LstmXcdBwdAr
 using namespace unetmi;
 
 extern "C" size_t unetmi_lstm_recurrence_xcd_workspace_bytes(void) {
-    return 64 * sizeof(unsigned) + (size_t)kXcds * 2 * kXH * kXCols * sizeof(unsigned long long);
+    return 64 * sizeof(unsigned) + (size_t)kXcds * 2 * kXHMax * kXCols * sizeof(unsigned long long);
 }
 
 static int lstm_xcd_run(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, int channel_major,
@@ -416,77 +424,90 @@ extern "C" int unetmi_lstm_recurrence_xcd_train(int T, int BP, int H, const floa
     return lstm_xcd_run(T, BP, H, wrec, gx_gates, hfull, 1, gx_gates, cell, ws, ws_bytes, stream);
 }
 
+// what the XCD-local kernels need from the device, common to the forward and the reverse recurrence
+static int lstm_xcd_device_ok(const char* who, int H, int BP) {
+    if (H != 640 && H != 300) return api_fail(UNETMI_E_UNSUPPORTED, std::string(who) + ": built for hidden sizes 640 and 300");
+    if (BP > kXcds * kXCols) return api_fail(UNETMI_E_UNSUPPORTED, std::string(who) + ": at most 32 batch columns per launch");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return api_fail(UNETMI_E_HIP, std::string(who) + ": cannot query the device");
+    // placement assumes 8 XCDs of 32 compute units: hidden size 640 takes one workgroup on every one of them,
+    // hidden size 300 (padded to 320) on 16 per XCD
+    if (cus != kXcds * 32) return api_fail(UNETMI_E_UNSUPPORTED, std::string(who) + ": needs 8 XCDs of 32 compute units");
+    return UNETMI_OK;
+}
+
+template <bool SAVE, int HP>
+static int lstm_xcd_launch(const LstmXcdArgs& a, void* ws, hipStream_t s) {
+    int per_cu = 0;
+    const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_kernel<SAVE, HP>, 256, 0);
+    if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd occupancy query: ") + hipGetErrorString(oe));
+    if (per_cu < 1) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: the kernel does not fit a compute unit");
+    // tickets, abort word and the state granules start from zero: h_0 = 0 carrying step tag 0
+    hipError_t e = hipMemsetAsync(ws, 0, unetmi_lstm_recurrence_xcd_workspace_bytes(), s);
+    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd memset: ") + hipGetErrorString(e));
+    hipLaunchKernelGGL((lstm_xcd_kernel<SAVE, HP>), dim3(kXcds * (HP / kXU)), dim3(256), 0, s, a);
+    e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd launch: ") + hipGetErrorString(e));
+}
+
 static int lstm_xcd_run(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, int channel_major,
                         float* gates, float* cell, void* ws, size_t ws_bytes, void* stream) {
     if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence_xcd: bad sizes");
     if (channel_major != 0 && channel_major != 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence_xcd: layout is 0 or 1");
-    if (H != kXH) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: built for hidden size 640");
-    if (BP > kXcds * kXCols) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: at most 32 batch columns per launch");
+    const int ok = lstm_xcd_device_ok("lstm_recurrence_xcd", H, BP);
+    if (ok != UNETMI_OK) return ok;
     if (T == 0) return UNETMI_OK;
     if (!wrec || !gx || !hfull || !ws) return api_fail(UNETMI_E_BAD_ARG, "lstm_recurrence_xcd: null pointer");
     if (ws_bytes < unetmi_lstm_recurrence_xcd_workspace_bytes())
         return api_fail(UNETMI_E_BAD_ARG, "lstm_recurrence_xcd: workspace too small");
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return api_fail(UNETMI_E_HIP, "lstm_recurrence_xcd: cannot query the device");
-    // one workgroup per compute unit, 32 compute units on each of 8 XCDs
-    if (cus != kXcds * kXWg) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: needs 8 XCDs of 32 compute units");
-    int per_cu = 0;
-    const hipError_t oe = gates ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_kernel<true>, 256, 0)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_kernel<false>, 256, 0);
-    if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd occupancy query: ") + hipGetErrorString(oe));
-    if (per_cu < 1) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: the kernel does not fit a compute unit");
     LstmXcdArgs a{};
-    a.wrec = wrec; a.gx = gx; a.hfull = hfull; a.T = T; a.BP = BP;
+    a.wrec = wrec; a.gx = gx; a.hfull = hfull; a.T = T; a.BP = BP; a.H = H;
     a.gates = gates; a.cell = cell;
     if (channel_major) {        // [rows][T+1][BP]: slot 0 of both is the state before the first step
         a.gx_step = BP; a.gx_row = (long long)(T + 1) * BP; a.gx_first = BP;
         a.h_step = BP; a.h_row = (long long)(T + 1) * BP;
     } else {
-        a.gx_step = (long long)4 * kXH * BP; a.gx_row = BP; a.gx_first = 0;
-        a.h_step = (long long)kXH * BP; a.h_row = BP;
+        a.gx_step = (long long)4 * H * BP; a.gx_row = BP; a.gx_first = 0;
+        a.h_step = (long long)((H + 15) / 16 * 16) * BP; a.h_row = BP;    // a step-major state slot is padded to 16 rows
     }
     a.ctl = static_cast<unsigned*>(ws);
     a.hx = reinterpret_cast<unsigned long long*>(static_cast<unsigned*>(ws) + 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // tickets, abort word and the state granules start from zero: h_0 = 0 carrying step tag 0
-    hipError_t e = hipMemsetAsync(ws, 0, unetmi_lstm_recurrence_xcd_workspace_bytes(), s);
-    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd memset: ") + hipGetErrorString(e));
-    if (gates) hipLaunchKernelGGL(lstm_xcd_kernel<true>, dim3(kXcds * kXWg), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(lstm_xcd_kernel<false>, dim3(kXcds * kXWg), dim3(256), 0, s, a);
-    e = hipGetLastError();
-    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd launch: ") + hipGetErrorString(e));
+    if (H == 640) return gates ? lstm_xcd_launch<true, 640>(a, ws, s) : lstm_xcd_launch<false, 640>(a, ws, s);
+    return gates ? lstm_xcd_launch<true, 320>(a, ws, s) : lstm_xcd_launch<false, 320>(a, ws, s);
 }
 
 extern "C" size_t unetmi_lstm_bptt_xcd_workspace_bytes(void) {
-    return 64 * sizeof(unsigned) + (size_t)kXcds * 2 * kXG * kXCols * sizeof(unsigned long long);
+    return 64 * sizeof(unsigned) + (size_t)kXcds * 2 * 4 * kXHMax * kXCols * sizeof(unsigned long long);
+}
+
+template <int HP>
+static int lstm_bptt_launch(const LstmXcdBwdArgs& a, void* ws, hipStream_t s) {
+    int per_cu = 0;
+    const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_bwd_kernel<HP>, 256, 0);
+    if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_bptt_xcd occupancy query: ") + hipGetErrorString(oe));
+    if (per_cu < 1) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_bptt_xcd: the kernel does not fit a compute unit");
+    // tickets, abort word and the granules start from zero: G_T = 0 carrying tag 0
+    hipError_t e = hipMemsetAsync(ws, 0, unetmi_lstm_bptt_xcd_workspace_bytes(), s);
+    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_bptt_xcd memset: ") + hipGetErrorString(e));
+    hipLaunchKernelGGL((lstm_xcd_bwd_kernel<HP>), dim3(kXcds * (HP / kXU)), dim3(256), 0, s, a);
+    e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_bptt_xcd launch: ") + hipGetErrorString(e));
 }
 
 extern "C" int unetmi_lstm_bptt_xcd(int T, int BP, int H, const float* wrec, float* gates, const float* cell,
                                     const float* dhfull, void* ws, size_t ws_bytes, void* stream) {
     if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_bptt_xcd: bad sizes");
-    if (H != kXH) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_bptt_xcd: built for hidden size 640");
-    if (BP > kXcds * kXCols) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_bptt_xcd: at most 32 batch columns per launch");
+    const int ok = lstm_xcd_device_ok("lstm_bptt_xcd", H, BP);
+    if (ok != UNETMI_OK) return ok;
     if (T == 0) return UNETMI_OK;
     if (!wrec || !gates || !cell || !dhfull || !ws) return api_fail(UNETMI_E_BAD_ARG, "lstm_bptt_xcd: null pointer");
     if (ws_bytes < unetmi_lstm_bptt_xcd_workspace_bytes()) return api_fail(UNETMI_E_BAD_ARG, "lstm_bptt_xcd: workspace too small");
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return api_fail(UNETMI_E_HIP, "lstm_bptt_xcd: cannot query the device");
-    if (cus != kXcds * kXWg) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_bptt_xcd: needs 8 XCDs of 32 compute units");
-    int per_cu = 0;
-    const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_bwd_kernel, 256, 0);
-    if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_bptt_xcd occupancy query: ") + hipGetErrorString(oe));
-    if (per_cu < 1) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_bptt_xcd: the kernel does not fit a compute unit");
     LstmXcdBwdArgs a{};
-    a.wrec = wrec; a.gates = gates; a.cell = cell; a.dhfull = dhfull; a.T = T; a.BP = BP;
+    a.wrec = wrec; a.gates = gates; a.cell = cell; a.dhfull = dhfull; a.T = T; a.BP = BP; a.H = H;
     a.ctl = static_cast<unsigned*>(ws);
     a.gxch = reinterpret_cast<unsigned long long*>(static_cast<unsigned*>(ws) + 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // tickets, abort word and the granules start from zero: G_T = 0 carrying tag 0
-    hipError_t e = hipMemsetAsync(ws, 0, unetmi_lstm_bptt_xcd_workspace_bytes(), s);
-    if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_bptt_xcd memset: ") + hipGetErrorString(e));
-    hipLaunchKernelGGL(lstm_xcd_bwd_kernel, dim3(kXcds * kXWg), dim3(256), 0, s, a);
-    e = hipGetLastError();
-    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_bptt_xcd launch: ") + hipGetErrorString(e));
+    return H == 640 ? lstm_bptt_launch<640>(a, ws, s) : lstm_bptt_launch<320>(a, ws, s);
 }

@@ -51,7 +51,7 @@ def _folded_recurrent_matrix(lstm, layer, cache):
 
 
 def _xcd_kernel_fits(dev, hidden):
-    return KERNEL == "xcd" and hidden == 640 and torch.cuda.get_device_properties(dev).multi_processor_count == 256
+    return KERNEL == "xcd" and hidden in (640, 300) and torch.cuda.get_device_properties(dev).multi_processor_count == 256
 
 
 def _recurrence(wrec, gx, hfull, use_xcd, channel_major=False):
@@ -172,10 +172,9 @@ PARAMS_PER_LAYER = ("weight_ih_l{}", "weight_hh_l{}", "bias_ih_l{}", "bias_hh_l{
 
 
 def trainable_on_device(lstm, x):
-    """lstm_forward_train serves this call: a projected LSTM of hidden size 640 on a device the XCD-local kernels
-    fit (H = 300 and other devices keep torch's device LSTM under autograd)."""
-    return (supported(lstm) and lstm.hidden_size == 640 and x.is_cuda and x.dtype == torch.float32
-            and _xcd_kernel_fits(x.device, lstm.hidden_size))
+    """lstm_forward_train serves this call: a projected LSTM of hidden size 640 or 300 (no dropout between the
+    layers) on a device the XCD-local kernels fit; other devices keep torch's device LSTM under autograd."""
+    return (supported(lstm) and x.is_cuda and x.dtype == torch.float32 and _xcd_kernel_fits(x.device, lstm.hidden_size))
 
 
 class RecurrenceAborted(RuntimeError):
@@ -259,7 +258,7 @@ def lstm_forward_train(lstm, x):
     """x [B, T, input] -> [B, T, proj] with autograd history: gradients reach x and every parameter of ``lstm``.
     Zero initial state.  Falls back to torch's LSTM for a call whose forward kernel reports an abort."""
     if not trainable_on_device(lstm, x):
-        raise NotImplementedError("lstm_forward_train: a projected fp32 LSTM of hidden size 640 on a 256-CU device")
+        raise NotImplementedError("lstm_forward_train: a projected fp32 LSTM of hidden size 640 or 300 on a 256-CU device")
     B = x.shape[0]
     if B > XCD_BATCH_PER_LAUNCH:                    # sequences are independent: run them in groups
         return torch.cat([lstm_forward_train(lstm, x[i:i + XCD_BATCH_PER_LAUNCH])
