@@ -241,6 +241,16 @@ int unetmi_lstm_recurrence(int T, int BP, int H, const float* wrec, const float*
 int unetmi_gru_recurrence(int T, int BP, int H, const float* whh, const float* bhh, const float* gx,
                           int gx_channel_major, float* hfull, void* sync_ws, void* stream);
 
+/* One time step of a GRU for M independent sequences at once -- the elementwise half of the bidirectional
+ * frequency-axis GRU (UDSS.py:15-37, UNet_m.py:615-638: nn.GRU(..., bidirectional=True) over B*T sequences of a few
+ * steps), whose recurrent half is then one library GEMM per step (gh = h W_hh^T):
+ *   r = sigmoid(gx_r + gh_r + b_hr), z = sigmoid(gx_z + gh_z + b_hz), n = tanh(gx_n + r (gh_n + b_hn)), h' = (1-z) n + z h.
+ * gx: row m at gx + m * gx_stride, 3H values (W_ih x + b_ih, gates r, z, n); gh [M][3H] contiguous or null (first step
+ * from a zero state: no product needed); bhh [3H]; hprev: row m at hprev + m * hprev_stride, or null (zero state);
+ * out: row m at out + m * out_stride, H values.  Strides in elements. */
+int unetmi_gru_gate_fwd(long long M, int H, const float* gx, long long gx_stride, const float* gh, const float* bhh,
+                        const float* hprev, long long hprev_stride, float* out, long long out_stride, void* stream);
+
 /* The GRU under autograd (train() mode of the TGRU bottlenecks and of cRNN, DSUNet.py:281-312, UDSS.py:39-70, :190-239;
  * the reference leaves the backward to torch autograd).  Step-major layouts, sizes and sync_ws as unetmi_gru_recurrence.
  *
@@ -324,6 +334,15 @@ int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const vo
 int unetmi_instnorm_act_fwd(int N, int C, int HW, const void* z, const float* gamma, const float* beta, float eps, int act,
                             const float* act_param, int act_param_per_channel, const float* gate, void* out, int dtype,
                             void* stream);
+
+/* LayerNorm + activation of an Encoder / Decoder built with norm="LayerNorm" (UNet_m.py:312-319, :355-362:
+ * nn.LayerNorm(out_channels) applied to the NCHW convolution output normalises each row (n, c, h) over its W values,
+ * so W must equal out_channels): out = gate[n,c] * act(gamma[w] * (z - mean_row) * rstd_row + beta[w]), biased
+ * variance, eps inside the root.  gamma / beta [W] and gate [N*C] may be null; act_param: one slope or one per
+ * channel.  One launch, one wave per row. */
+int unetmi_layernorm_w_act_fwd(int N, int C, int H, int W, const void* z, const float* gamma, const float* beta, float eps,
+                               int act, const float* act_param, int act_param_per_channel, const float* gate, void* out,
+                               int dtype, void* stream);
 
 /* Gate stage of DSUNet's gated convolutions (GConv / TrGConv, DSUNet.py:134-172, :241-275), which compute
  * sigmoid(conv_m(x)) * conv_c(x) [-> norm -> activation].  The two convolutions share geometry and input, so

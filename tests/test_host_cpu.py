@@ -333,6 +333,8 @@ def test_every_entry_point_is_a_dispatcher_op_with_shape_inference():
         assert yb.shape == z.shape and mb.shape == ib.shape == (8,)
         status = ops.gru_recurrence(torch.empty(384, 128), torch.empty(384), torch.empty(5, 384, 16), torch.empty(6, 128, 16), False)
         assert status.shape == () and status.dtype == torch.int32
+        assert ops.layernorm_w_act(z, None, None, 1e-5, 1, torch.empty(1), None).shape == z.shape
+        assert ops.gru_gate(torch.empty(7, 2, 768), 0, 1, None, torch.empty(384), torch.empty(7, 2, 256), -1) is None
         status = ops.gru_recurrence_train(torch.empty(384, 128), torch.empty(384), torch.empty(5, 384, 16), torch.empty(6, 128, 16),
                                           torch.empty(5, 512, 16))
         assert status.shape == () and status.dtype == torch.int32

@@ -791,6 +791,74 @@ def test_instance_norm_blocks_one_launch(device, case, dtype):
     assert instance_norm_act(z.to(device).float(), tracked.to(device), nn.ReLU(), None) is None
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [("LeakyReLU", True, False), ("PReLU", True, True), ("SiLU", False, True), ("Tanh", True, False)])
+def test_layer_norm_blocks_one_launch(device, case, dtype):
+    """Encoder / Decoder built with norm="LayerNorm" (UNet_m.py:312-319: nn.LayerNorm(out_channels) on the NCHW
+    convolution output, i.e. over the time axis, which must be as long as there are channels): the HIP convolution, then
+    LayerNorm + activation (+ gate) as one launch, against the torch CPU modules; rows of 70 and of 10 values."""
+    import torch.nn as nn
+    import unet_amd
+    from unet_amd.fused import layer_norm_act
+    act_name, affine, with_gate = case
+    g = torch.Generator().manual_seed(19)
+    for C, H, W in ((10, 33, 70), (10, 5, 10)):
+        z = (torch.randn(3, C, H, W, generator=g) * 1.7 + 11.0).to(dtype)
+        norm = nn.LayerNorm(W, elementwise_affine=affine)
+        act = {"LeakyReLU": nn.LeakyReLU(0.1), "PReLU": nn.PReLU(C), "SiLU": nn.SiLU(), "Tanh": nn.Tanh()}[act_name]
+        with torch.no_grad():
+            if affine:
+                norm.weight.copy_(torch.rand(W, generator=g) + 0.5)
+                norm.bias.copy_(torch.randn(W, generator=g) * 0.2)
+            if act_name == "PReLU":
+                act.weight.copy_(torch.linspace(-0.2, 0.5, C))
+            gate = torch.rand(3, C, generator=g) if with_gate else None
+            want = act(norm(z.float()))
+            if gate is not None:
+                want = want * gate[:, :, None, None]
+        got = layer_norm_act(z.to(device), norm.to(device), act.to(device), None if gate is None else gate.to(device))
+        assert got is not None and got.dtype == dtype
+        assert_close(got.float(), want, tol=1e-4 if dtype == torch.float32 else 6e-3, what="LayerNorm(T) + " + act_name)
+        norm.cpu(), act.cpu()
+    # a LayerNorm over another shape than the last axis is not this kernel's case
+    assert layer_norm_act(z.to(device).float(), nn.LayerNorm(7).to(device), nn.ReLU(), None) is None
+    if dtype == torch.float32 and not with_gate:
+        # the whole block through the reference's constructor: 12 output channels need 12 time frames
+        ref_conv = nn.Conv2d(6, 12, (5, 3), (2, 1), (2, 1))
+        dev = unet_amd.Encoder(6, 12, (5, 3), (2, 1), (2, 1), norm="LayerNorm", activation="LeakyReLU").eval()
+        with torch.no_grad():
+            ref_conv.weight.copy_(dev.conv.weight)
+            ref_conv.bias.copy_(dev.conv.bias)
+            dev.bn.weight.copy_(torch.rand(12, generator=g) + 0.5)
+            dev.bn.bias.copy_(torch.randn(12, generator=g) * 0.2)
+            x = torch.randn(2, 6, 31, 12, generator=g)
+            want = nn.functional.leaky_relu(nn.functional.layer_norm(ref_conv(x), (12,), dev.bn.weight, dev.bn.bias), 0.01)
+            got = dev.to(device)(x.to(device))
+        assert_close(got, want, what="Encoder(norm='LayerNorm')")
+
+
+@pytest.mark.parametrize("n_in,hidden,L,M,bidir", [(64, 128, 2, 1500, True), (24, 40, 5, 333, True), (32, 64, 3, 64, False)])
+def test_wide_gru_over_many_short_sequences(device, n_in, hidden, L, M, bidir):
+    """The frequency-axis GRU (UDSS.py:15-37, UNet_m.py:615-638: nn.GRU(..., bidirectional=True) over B*T sequences
+    of a few frequency rows) as one matrix product and one gate launch per step and direction
+    (unet_amd.gru.wide_forward) against torch's CPU GRU."""
+    import copy
+    import unet_amd
+    from unet_amd.gru import wide_forward, wide_supported
+    from unet_amd.seeding import normal
+    ref = torch.nn.GRU(n_in, hidden, batch_first=True, bidirectional=bidir).eval()
+    holder = torch.nn.Module()
+    holder.gru = ref
+    unet_amd.seeded_fill_(holder, seed=83)
+    x = normal("wide_gru/x", (M, L, n_in), seed=83)
+    with torch.no_grad():
+        want = ref(x)[0]
+    dev_gru = copy.deepcopy(ref).to(device)
+    assert wide_supported(dev_gru, x.to(device)) and not wide_supported(dev_gru.train(), x.to(device))
+    got = wide_forward(dev_gru.eval(), x.to(device))
+    assert_close(got, want, tol=2e-5, what="wide GRU, {} direction(s), {} steps".format(2 if bidir else 1, L))
+
+
 @pytest.mark.parametrize("shape", [(192, 300, 192, 3), (210, 300, 210, 3)])
 @pytest.mark.parametrize("B,T", [(2, 33), (32, 12), (70, 5)])
 def test_projected_lstm_hidden_300(device, shape, B, T):

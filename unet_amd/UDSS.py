@@ -397,7 +397,8 @@ class TGRUBlock(_ComplexBlock):
 
 
 class FGRUBlock(_ComplexBlock):
-    """Bidirectional GRU along frequency for every (batch, frame) (torch's device GRU), then complex 1x1 conv +
+    """Bidirectional GRU along frequency for every (batch, frame) (unet_amd.gru.wide_forward in eval mode: a matrix
+    product and one gate launch per step and direction; torch's device GRU under autograd), then complex 1x1 conv +
     complex BatchNorm + PReLU as one launch (UDSS.py:15-37)."""
 
     def __init__(self, in_channels, hidden_size, out_channels):
@@ -413,7 +414,11 @@ class FGRUBlock(_ComplexBlock):
         B, C2, F, T = x.shape
         C = C2 // 2
         seq = x.reshape(B, 2, C, F, T).permute(0, 4, 3, 2, 1).reshape(B * T, F, C2)      # feature index c*2 + re/im
-        y, _ = self.GRU(seq.float())
+        seq = seq.float().contiguous()
+        if _gru.wide_supported(self.GRU, seq):          # eval: one product + one gate launch per step and direction
+            y = _gru.wide_forward(self.GRU, seq)
+        else:
+            y, _ = self.GRU(seq)
         H2 = self.hidden_size * 2
         y = y.reshape(B, T, F, H2, 2).permute(0, 4, 3, 2, 1).reshape(B, 2 * H2, F, T).contiguous().to(x.dtype)
         return self._stacked(self.conv, y)

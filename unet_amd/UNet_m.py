@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .fused import FusedConv, instance_norm_act, _pair, require_device_tensor
+from .fused import FusedConv, instance_norm_act, layer_norm_act, _pair, require_device_tensor
 from .ops import dwconv2d_fwd, resblock_layer
 
 
@@ -158,6 +158,8 @@ class _FusedBlock(nn.Module):
             return layer(x, skip, in_mode=in_mode, gate=gate, residual=residual)
         y = layer(x, skip, in_mode=in_mode, epilogue=False)
         fused = instance_norm_act(y, self.bn, self.acti, gate)       # InstanceNorm2d + activation (+ gate): one launch
+        if fused is None:
+            fused = layer_norm_act(y, self.bn, self.acti, gate)      # LayerNorm over the time axis, likewise
         if fused is not None:
             return fused if residual is None else fused + residual
         y = self.acti(self.bn(y))

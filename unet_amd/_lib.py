@@ -56,9 +56,11 @@ EXPORTED_SYMBOLS = (
     "unetmi_lstm_bptt_xcd",
     "unetmi_gru_recurrence",
     "unetmi_gru_recurrence_train",
+    "unetmi_gru_gate_fwd",
     "unetmi_gru_bptt",
     "unetmi_glu_fwd",
     "unetmi_instnorm_act_fwd",
+    "unetmi_layernorm_w_act_fwd",
     "unetmi_conv2d_b16_packed_weight_bytes",
     "unetmi_conv2d_b16_kernel_name",
     "unetmi_conv2d_b16_pack_weights",
@@ -162,10 +164,15 @@ def _load():
     lib.unetmi_gru_recurrence_train.restype = ctypes.c_int
     lib.unetmi_gru_bptt.argtypes = [ci] * 3 + [fp] * 5 + [vp, vp]
     lib.unetmi_gru_bptt.restype = ctypes.c_int
+    ll = ctypes.c_longlong
+    lib.unetmi_gru_gate_fwd.argtypes = [ll, ci, fp, ll, fp, fp, fp, ll, fp, ll, vp]
+    lib.unetmi_gru_gate_fwd.restype = ctypes.c_int
     lib.unetmi_glu_fwd.argtypes = [ci] * 3 + [fp] * 3 + [ci] + [fp] * 3 + [ci, vp]
     lib.unetmi_glu_fwd.restype = ctypes.c_int
     lib.unetmi_instnorm_act_fwd.argtypes = [ci] * 3 + [fp] * 3 + [cf, ci, fp, ci, fp, fp, ci, vp]
     lib.unetmi_instnorm_act_fwd.restype = ctypes.c_int
+    lib.unetmi_layernorm_w_act_fwd.argtypes = [ci] * 4 + [fp] * 3 + [cf, ci, fp, ci, fp, fp, ci, vp]
+    lib.unetmi_layernorm_w_act_fwd.restype = ctypes.c_int
     lib.unetmi_adam_step.argtypes = [sz] + [fp] * 4 + [cf] * 6 + [ci, vp]
     lib.unetmi_conv2d_b16_packed_weight_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.unetmi_conv2d_b16_packed_weight_bytes.restype = sz

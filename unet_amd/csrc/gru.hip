@@ -175,6 +175,34 @@ static int launch_gru(const GruArgs& a, int cus, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// One step of a GRU over MANY short sequences (the bidirectional frequency-axis GRU of UDSS.py:15-37 / UNet_m.py:
+// 615-638: B*T sequences of two or a few steps): the recurrent product of a step is then one large matrix product
+// (a library GEMM by the caller), and what is left is this elementwise kernel,
+//     r = sigmoid(gx_r + gh_r + b_hr)   z = sigmoid(gx_z + gh_z + b_hz)   n = tanh(gx_n + r (gh_n + b_hn))
+//     h' = (1 - z) n + z h,
+// with row strides so that gx is read out of the all-steps / both-directions product and h' lands in the caller's
+// [M, L, 2H] output directly.  gh == null and hprev == null: the first step from a zero state.
+__global__ __launch_bounds__(256) void gru_gate_kernel(long long M, int H, const float* __restrict__ gx, long long gx_stride,
+                                                       const float* __restrict__ gh, const float* __restrict__ bhh,
+                                                       const float* __restrict__ hprev, long long hprev_stride,
+                                                       float* __restrict__ out, long long out_stride) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * H) return;
+    const long long m = i / H;
+    const int u = (int)(i - m * H);
+    const float* gxr = gx + m * gx_stride;
+    float hr = bhh[u], hz = bhh[H + u], hn = bhh[2 * H + u];
+    if (gh) {
+        const float* g = gh + m * 3 * (long long)H;
+        hr += g[u]; hz += g[H + u]; hn += g[2 * H + u];
+    }
+    const float r = gru_sigmoid(gxr[u] + hr), z = gru_sigmoid(gxr[H + u] + hz);
+    const float n = fast_tanh(gxr[2 * H + u] + r * hn);
+    const float h = hprev ? hprev[m * hprev_stride + u] : 0.f;
+    out[m * out_stride + u] = (1.f - z) * n + z * h;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Backpropagation through time.  With dh_t the gradient reaching h_t (from the output and from step t+1),
 //     dn = dh (1 - z),  dz = dh (h_{t-1} - n),  a_n = dn (1 - n^2),  a_r = a_n q r (1 - r),  a_z = dz z (1 - z),  dq = a_n r,
 //     dh_{t-1} = dh z + W_hh^T [a_r; a_z; dq].
@@ -324,6 +352,20 @@ using namespace unetmi;
 
 static int gru_run(int T, int BP, int H, const float* whh, const float* bhh, const float* gx, int gx_channel_major,
                    float* hfull, float* gates, void* sync_ws, void* stream);
+
+extern "C" int unetmi_gru_gate_fwd(long long M, int H, const float* gx, long long gx_stride, const float* gh, const float* bhh,
+                                   const float* hprev, long long hprev_stride, float* out, long long out_stride, void* stream) {
+    if (M < 0 || H < 1 || gx_stride < 3ll * H || out_stride < H || (hprev && hprev_stride < H))
+        return api_fail(UNETMI_E_BAD_DESC, "gru_gate: bad sizes");
+    if (M == 0) return UNETMI_OK;
+    if (!gx || !bhh || !out) return api_fail(UNETMI_E_BAD_ARG, "gru_gate: null pointer");
+    const long long blocks = (M * H + 255) / 256;
+    if (blocks > 0x7fffffffll) return api_fail(UNETMI_E_UNSUPPORTED, "gru_gate: too many elements");
+    hipLaunchKernelGGL(gru_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), M, H, gx, gx_stride,
+                       gh, bhh, hprev, hprev_stride, out, out_stride);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("gru_gate launch: ") + hipGetErrorString(e));
+}
 
 extern "C" int unetmi_gru_recurrence(int T, int BP, int H, const float* whh, const float* bhh, const float* gx,
                                      int gx_channel_major, float* hfull, void* sync_ws, void* stream) {

@@ -171,6 +171,44 @@ __global__ __launch_bounds__(256) void instnorm_act_kernel(const void* __restric
         st_act<BF16>(out, base + i, in_act(act, fmaf(ld_act<BF16>(z, base + i), g, b), ap) * gt);
 }
 
+// nn.LayerNorm(W) on an NCHW tensor normalises every ROW (n, c, h) over its W values, with gamma / beta indexed by the
+// position in the row (what an Encoder / Decoder built with norm="LayerNorm" does, UNet_m.py:312-319: nn.LayerNorm(
+// out_channels) applied to [B, C, F, T] needs T == out_channels), followed here by the block's activation and gate.
+// One wave per row, four rows per workgroup; the row is read twice (statistics, then normalise) and stays in cache.
+template <bool BF16>
+__global__ __launch_bounds__(256) void rownorm_act_kernel(const void* __restrict__ z, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ act_param,
+                                                          int act_pc, const float* __restrict__ gate, void* __restrict__ out,
+                                                          int C, int H, int W, long long rows, float eps, int act) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;                          // whole waves leave: no barrier in this kernel
+    const int lane = threadIdx.x & 63;
+    const size_t base = (size_t)row * W;
+    const long long nc = row / H;
+    const int c = (int)(nc % C);
+    const float x0 = ld_act<BF16>(z, base);
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = lane; i < W; i += 64) {
+        const float d = ld_act<BF16>(z, base + i) - x0;
+        s0 += d;
+        s1 = fmaf(d, d, s1);
+    }
+    double d0 = s0, d1 = s1;
+    for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o, 64); d1 += __shfl_xor(d1, o, 64); }
+    const double md = d0 / W;
+    double var = d1 / W - md * md;
+    if (var < 0.0) var = 0.0;
+    const float mean = x0 + (float)md;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float ap = act_param ? act_param[act_pc ? c : 0] : 0.f;
+    const float gt = gate ? gate[nc] : 1.f;
+    for (int i = lane; i < W; i += 64) {
+        const float xh = (ld_act<BF16>(z, base + i) - mean) * rstd;
+        const float u = gamma ? fmaf(xh, gamma[i], beta ? beta[i] : 0.f) : xh;
+        st_act<BF16>(out, base + i, in_act(act, u, ap) * gt);
+    }
+}
+
 // out[n,k,f,t] = (tanh(y[n,k,f,t]) + eps) * x[n,k,f,t], x having Cx >= K channels (first K used)
 template <bool BF16>
 __global__ __launch_bounds__(256) void tanh_mask_kernel(const void* __restrict__ y, const void* __restrict__ x,
@@ -326,6 +364,30 @@ int unetmi_instnorm_act_fwd(int N, int C, int HW, const void* z, const float* ga
     else return api_fail(UNETMI_E_BAD_DESC, "instnorm_act: unknown dtype");
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("instnorm_act launch: ") + hipGetErrorString(e));
+}
+
+int unetmi_layernorm_w_act_fwd(int N, int C, int H, int W, const void* z, const float* gamma, const float* beta, float eps,
+                               int act, const float* act_param, int act_param_per_channel, const float* gate, void* out,
+                               int dtype, void* stream) {
+    if (N < 0 || C < 1 || H < 1 || W < 1) return api_fail(UNETMI_E_BAD_DESC, "layernorm_w_act: bad sizes");
+    if (act < UNETMI_ACT_NONE || act > UNETMI_ACT_GELU) return api_fail(UNETMI_E_BAD_DESC, "layernorm_w_act: unknown activation");
+    if (N == 0) return UNETMI_OK;
+    if (!z || !out) return api_fail(UNETMI_E_BAD_ARG, "layernorm_w_act: null tensor pointer");
+    if (beta && !gamma) return api_fail(UNETMI_E_BAD_ARG, "layernorm_w_act: beta without gamma");
+    if (act == UNETMI_ACT_LEAKY && !act_param) return api_fail(UNETMI_E_BAD_ARG, "layernorm_w_act: LeakyReLU / PReLU needs its slope");
+    const long long rows = (long long)N * C * H;
+    if ((rows + 3) / 4 > 0x7fffffffll) return api_fail(UNETMI_E_UNSUPPORTED, "layernorm_w_act: too many rows");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == UNETMI_DTYPE_BF16)
+        hipLaunchKernelGGL(rownorm_act_kernel<true>, grid, dim3(256), 0, s, z, gamma, beta, act_param, act_param_per_channel, gate,
+                           out, C, H, W, rows, eps, act);
+    else if (dtype == UNETMI_DTYPE_F32)
+        hipLaunchKernelGGL(rownorm_act_kernel<false>, grid, dim3(256), 0, s, z, gamma, beta, act_param, act_param_per_channel, gate,
+                           out, C, H, W, rows, eps, act);
+    else return api_fail(UNETMI_E_BAD_DESC, "layernorm_w_act: unknown dtype");
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("layernorm_w_act launch: ") + hipGetErrorString(e));
 }
 
 int unetmi_tanh_mask_mul(int N, int K, int Cx, int F, int T, float eps, const void* y, const void* x, void* out,

@@ -78,6 +78,32 @@ def instance_norm_act(z, norm, act, gate=None):
     return instnorm_act(z, gamma, beta, norm.eps, code, ap, None if gate is None else gate.float().contiguous())
 
 
+def layer_norm_act(z, norm, act, gate=None):
+    """act(norm(z)) [* gate] for an nn.LayerNorm over the LAST axis of z [N,C,H,W] (what nn.LayerNorm(out_channels)
+    does to an Encoder's / Decoder's NCHW output, UNet_m.py:312-319) as ONE launch (unetmi_layernorm_w_act_fwd), or
+    None when norm / act / z are not such a case."""
+    if not isinstance(norm, nn.LayerNorm) or z.dim() != 4 or not z.is_contiguous():
+        return None
+    if tuple(norm.normalized_shape) != (z.shape[3],):
+        return None
+    found = activation_code(act)
+    if found is None:
+        return None
+    code, par = found
+    if isinstance(par, torch.Tensor):
+        ap = par.detach().float().reshape(-1).contiguous()
+    elif par is not None:
+        ap = torch.full((1,), float(par), dtype=torch.float32, device=z.device)
+    else:
+        ap = None
+    from .ops import layernorm_w_act
+    gamma = norm.weight.detach().float().contiguous() if norm.weight is not None else None
+    beta = norm.bias.detach().float().contiguous() if norm.bias is not None else None
+    if gamma is None and beta is not None:
+        return None
+    return layernorm_w_act(z, gamma, beta, norm.eps, code, ap, None if gate is None else gate.float().contiguous())
+
+
 def require_device_tensor(x, who):
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
         raise RuntimeError(

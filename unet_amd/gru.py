@@ -82,6 +82,41 @@ def gru_forward(gru, x, h0=None):
         return y, y[:, -1].unsqueeze(0).contiguous() if T > 0 else hfull[0, :, :B].t().unsqueeze(0).contiguous()
 
 
+def wide_supported(gru, x=None):
+    """A single-layer batch_first GRU (one or two directions) in eval mode, for wide_forward."""
+    ok = isinstance(gru, nn.GRU) and gru.num_layers == 1 and gru.batch_first and gru.bias and not gru.training
+    if ok and x is not None:
+        ok = x.is_cuda and x.dim() == 3 and x.dtype == torch.float32
+    return ok
+
+
+def wide_forward(gru, x):
+    """x [M, L, input] -> y [M, L, D*H] for MANY short sequences (the frequency-axis GRU of UDSS.py:15-37: M = B*T in
+    the thousands, L = a few frequency rows, D = 2 directions): every step is one matrix product over all sequences
+    (torch.matmul) and one launch for the gates (unetmi_gru_gate_fwd) -- the persistent recurrence kernel is built for
+    the opposite case, a few long sequences.  Zero initial state, inference only; returns y alone."""
+    if not wide_supported(gru, x):
+        raise NotImplementedError("wide_forward: a single-layer batch_first fp32 GRU in eval mode on the device")
+    M, L, _ = x.shape
+    H, D = gru.hidden_size, 2 if gru.bidirectional else 1
+    with torch.no_grad(), torch.cuda.device(x.device):
+        names = [""] + (["_reverse"] if D == 2 else [])
+        w_ih = torch.cat([getattr(gru, "weight_ih_l0" + n).detach().float() for n in names], dim=0)      # [D*3H, in]
+        b_ih = torch.cat([getattr(gru, "bias_ih_l0" + n).detach().float() for n in names], dim=0)
+        gx = torch.addmm(b_ih, x.reshape(M * L, -1), w_ih.t()).view(M, L, D * 3 * H)
+        y = torch.empty((M, L, D * H), dtype=torch.float32, device=x.device)
+        for d, n in enumerate(names):
+            w_hh = getattr(gru, "weight_hh_l0" + n).detach().float()
+            b_hh = getattr(gru, "bias_hh_l0" + n).detach().float().contiguous()
+            order = range(L) if d == 0 else range(L - 1, -1, -1)
+            prev = -1
+            for step in order:
+                gh = None if prev < 0 else torch.matmul(y[:, prev, d * H:(d + 1) * H], w_hh.t())
+                _ops.gru_gate(gx, step, d, gh, b_hh, y, prev)
+                prev = step
+    return y
+
+
 class RecurrenceAborted(RuntimeError):
     """A persistent recurrence kernel gave up waiting for a workgroup that was not resident."""
 

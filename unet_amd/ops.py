@@ -239,6 +239,7 @@ _LIBRARY.define("tanh_mask_mul(Tensor y, Tensor x, float eps) -> Tensor")
 _LIBRARY.define("crf_apply(Tensor H, Tensor X) -> Tensor")
 _LIBRARY.define("glu(Tensor z, Tensor? scale, Tensor? shift, int act, Tensor? act_param, Tensor? gate) -> Tensor")
 _LIBRARY.define("instnorm_act(Tensor z, Tensor? gamma, Tensor? beta, float eps, int act, Tensor? act_param, Tensor? gate) -> Tensor")
+_LIBRARY.define("layernorm_w_act(Tensor z, Tensor? gamma, Tensor? beta, float eps, int act, Tensor? act_param, Tensor? gate) -> Tensor")
 _LIBRARY.define("pwconv64(Tensor x, Tensor? x2, Tensor weight, Tensor? bias, Tensor scale, Tensor shift, Tensor? slope, "
                 "bool act_first, bool residual) -> Tensor")
 _LIBRARY.define("resblock_layer(Tensor x, Tensor? x2, Tensor dw_weight, Tensor? dw_bias, Tensor pw_weight, "
@@ -397,7 +398,33 @@ def _instnorm_act_cuda(z, gamma, beta, eps, act, act_param, gate):
     return out
 
 
+def _layernorm_w_act_cuda(z, gamma, beta, eps, act, act_param, gate):
+    """act(LayerNorm over the last axis of z [N,C,H,W], gamma / beta [W]) * gate[n,c] as one launch."""
+    code = dtype_code(z)
+    _dev(z, "z", "layernorm_w_act", z.dtype)
+    if z.dim() != 4:
+        raise ValueError("unetmi::layernorm_w_act: z must be [N,C,H,W]")
+    N, C, H, W = z.shape
+    for t, name, numel in ((gamma, "gamma", W), (beta, "beta", W), (gate, "gate", N * C)):
+        if t is not None:
+            _dev(t, name, "layernorm_w_act")
+            if t.numel() != numel:
+                raise ValueError("unetmi::layernorm_w_act: {} has {} elements, expected {}".format(name, t.numel(), numel))
+    act_pc = 0
+    if act_param is not None:
+        _dev(act_param, "act_param", "layernorm_w_act")
+        if act_param.numel() not in (1, C):
+            raise ValueError("unetmi::layernorm_w_act: act_param needs 1 or {} elements".format(C))
+        act_pc = int(act_param.numel() > 1)
+    out = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        check(_lib.lib.unetmi_layernorm_w_act_fwd(N, C, H, W, _ptr(z), _ptr(gamma), _ptr(beta), eps, act, _ptr(act_param), act_pc,
+                                                  _ptr(gate), _ptr(out), code, _stream(z)), "unetmi_layernorm_w_act_fwd")
+    return out
+
+
 _LIBRARY.impl("instnorm_act", _instnorm_act_cuda, "CUDA")
+_LIBRARY.impl("layernorm_w_act", _layernorm_w_act_cuda, "CUDA")
 _LIBRARY.impl("glu", _glu_cuda, "CUDA")
 _LIBRARY.impl("pwconv64", _pwconv64_cuda, "CUDA")
 _LIBRARY.impl("dwconv2d_fwd", _dwconv2d_fwd_cuda, "CUDA")
@@ -412,6 +439,11 @@ def _(x, x2, weight, bias, padding, dilation):
 
 
 @torch.library.register_fake("unetmi::instnorm_act")
+def _(z, gamma, beta, eps, act, act_param, gate):
+    return torch.empty_like(z)
+
+
+@torch.library.register_fake("unetmi::layernorm_w_act")
 def _(z, gamma, beta, eps, act, act_param, gate):
     return torch.empty_like(z)
 
@@ -449,6 +481,7 @@ resblock_layer = torch.ops.unetmi.resblock_layer
 pwconv64 = torch.ops.unetmi.pwconv64
 glu = torch.ops.unetmi.glu
 instnorm_act = torch.ops.unetmi.instnorm_act
+layernorm_w_act = torch.ops.unetmi.layernorm_w_act
 
 
 # ---------------------------------------------------------------------------------------
@@ -475,6 +508,7 @@ _LIBRARY.define("lstm_bptt(Tensor wrec, Tensor(a!) gates, Tensor cell, Tensor dh
 _LIBRARY.define("gru_recurrence(Tensor whh, Tensor bhh, Tensor gx, Tensor(a!) hfull, bool channel_major) -> Tensor")
 _LIBRARY.define("gru_recurrence_train(Tensor whh, Tensor bhh, Tensor gx, Tensor(a!) hfull, Tensor(b!) gates) -> Tensor")
 _LIBRARY.define("gru_bptt(Tensor whh, Tensor(a!) gates, Tensor hfull, Tensor dy) -> (Tensor, Tensor)")
+_LIBRARY.define("gru_gate(Tensor gx, int step, int direction, Tensor? gh, Tensor bhh, Tensor(a!) y, int prev_step) -> ()")
 _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
 _LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
 _LIBRARY.define("conv2d_b16_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
@@ -798,6 +832,29 @@ def _gru_bptt_cuda(whh, gates, hfull, dy):
     return dh0, sync[H // 16].clone()
 
 
+def _gru_gate_cuda(gx, step, direction, gh, bhh, y, prev_step):
+    """One step of a (bi)directional GRU over many sequences: gx [M, L, D*3H] (input products of all steps and
+    directions), gh [M, 3H] (this step's recurrent product) or None, y [M, L, D*H]; reads the previous state from
+    y[:, prev_step, direction*H:...] (prev_step < 0: zero state) and writes y[:, step, direction*H:...]."""
+    for t, name in ((gx, "gx"), (bhh, "bhh"), (y, "y")):
+        _dev(t, name, "gru_gate")
+    M, L, G = gx.shape
+    H = bhh.numel() // 3
+    D = G // (3 * H)
+    if G != D * 3 * H or tuple(y.shape) != (M, L, D * H) or not (0 <= step < L and 0 <= direction < D and prev_step < L):
+        raise ValueError("unetmi::gru_gate: gx [M,L,D*3H], bhh [3H], y [M,L,D*H] expected")
+    if gh is not None:
+        _dev(gh, "gh", "gru_gate")
+        if tuple(gh.shape) != (M, 3 * H):
+            raise ValueError("unetmi::gru_gate: gh must be [M, 3H]")
+    gx_p = gx.data_ptr() + 4 * (step * G + direction * 3 * H)
+    out_p = y.data_ptr() + 4 * (step * D * H + direction * H)
+    prev_p = None if prev_step < 0 else y.data_ptr() + 4 * (prev_step * D * H + direction * H)
+    with torch.cuda.device(gx.device):
+        check(_lib.lib.unetmi_gru_gate_fwd(M, H, gx_p, L * G, _ptr(gh), _ptr(bhh), prev_p, L * D * H, out_p, L * D * H, _stream(gx)),
+              "unetmi_gru_gate_fwd")
+
+
 def blocks_for(C):
     return 2 * ((C + 15) // 16)
 
@@ -939,7 +996,7 @@ for _name, _fn in (("bn_train_stats", _bn_train_stats_cuda), ("bn_batch_stats", 
                    ("bn_running_update", _bn_running_update_cuda), ("bn_act_fwd", _bn_act_fwd_cuda),
                    ("bn_act_bwd", _bn_act_bwd_cuda), ("conv2d_wgrad", _conv2d_wgrad_cuda),
                    ("adam_step", _adam_step_cuda), ("gather_f32", _gather_f32_cuda), ("lstm_recurrence", _lstm_recurrence_cuda),
-                   ("lstm_recurrence_train", _lstm_recurrence_train_cuda), ("lstm_bptt", _lstm_bptt_cuda), ("gru_recurrence", _gru_recurrence_cuda),
+                   ("lstm_recurrence_train", _lstm_recurrence_train_cuda), ("lstm_bptt", _lstm_bptt_cuda), ("gru_recurrence", _gru_recurrence_cuda), ("gru_gate", _gru_gate_cuda),
                    ("gru_recurrence_train", _gru_recurrence_train_cuda), ("gru_bptt", _gru_bptt_cuda), ("dwconv2d_wgrad", _dwconv2d_wgrad_cuda),
                    ("blocked_from_nchw", _blocked_from_nchw_cuda), ("nchw_from_blocked", _nchw_from_blocked_cuda),
                    ("conv2d_b16_fwd", _conv2d_b16_fwd_cuda), ("conv2d_b16_head_fwd", _conv2d_b16_head_fwd_cuda),
@@ -1014,6 +1071,11 @@ def _(whh, bhh, gx, hfull, channel_major):
     return gx.new_empty((), dtype=torch.int32)
 
 
+@torch.library.register_fake("unetmi::gru_gate")
+def _(gx, step, direction, gh, bhh, y, prev_step):
+    return None
+
+
 @torch.library.register_fake("unetmi::gru_recurrence_train")
 def _(whh, bhh, gx, hfull, gates):
     return gx.new_empty((), dtype=torch.int32)
@@ -1082,6 +1144,7 @@ lstm_recurrence_train = torch.ops.unetmi.lstm_recurrence_train
 lstm_bptt = torch.ops.unetmi.lstm_bptt
 gru_recurrence = torch.ops.unetmi.gru_recurrence
 gru_recurrence_train = torch.ops.unetmi.gru_recurrence_train
+gru_gate = torch.ops.unetmi.gru_gate
 gru_bptt = torch.ops.unetmi.gru_bptt
 dwconv2d_wgrad = torch.ops.unetmi.dwconv2d_wgrad
 blocked_from_nchw = torch.ops.unetmi.blocked_from_nchw
