@@ -57,7 +57,8 @@ enum {
  * store) and the pointers below, typed for the fp32 case, address 2-byte elements. */
 enum {
     UNETMI_DTYPE_F32 = 0,
-    UNETMI_DTYPE_BF16 = 1
+    UNETMI_DTYPE_BF16 = 1,
+    UNETMI_DTYPE_F16 = 2        /* blocked 16-bit tensors of the unetmi_conv2d_b16_* family only */
 };
 
 /* How the second input tensor combines with the first. */
@@ -364,7 +365,14 @@ int unetmi_glu_fwd(int N, int K, int HW, const void* z, const float* scale, cons
  *   in_mode      UNETMI_IN_SINGLE or UNETMI_IN_CONCAT (no add, no residual), K <= 128,
  *   reserved[1]  weight halves: 0/1 = weights rounded to bfloat16; 2 = a second image holds the rounding
  *                remainder and a second MFMA adds it (fp32-weight accuracy at twice the matrix work),
- *   reserved[2]  1: write out as plain fp32 NCHW [N,K,OH,OW] instead of the blocked layout (heads). */
+ *   reserved[2]  bits: UNETMI_B16_OUT_NCHW_F32 = write out as plain fp32 NCHW [N,K,OH,OW] instead of the blocked
+ *                layout (heads); UNETMI_B16_IN_F16 = both inputs and the weight image hold fp16 instead of bfloat16
+ *                (same layout, same matrix rate, three more mantissa bits; a layer's inputs share one format);
+ *                UNETMI_B16_OUT_F16 = the blocked output is stored as fp16 (values beyond +-65504 saturate).
+ *                fp16 suits tensors of known modest range -- activations behind a BatchNorm -- and cuts the
+ *                rounding error of a chain of layers about eightfold; a network input of unknown scale stays
+ *                bfloat16. */
+enum { UNETMI_B16_OUT_NCHW_F32 = 1, UNETMI_B16_IN_F16 = 2, UNETMI_B16_OUT_F16 = 4 };
 size_t unetmi_conv2d_b16_packed_weight_bytes(const UnetmiConvDesc* d);
 /* HOST function, a measurement aid like unetmi_conv2d_kernel_name: the kernel instantiation unetmi_conv2d_b16_fwd
  * (head_channels = 0) or unetmi_conv2d_b16_head_fwd launches for this descriptor, e.g. "conv_b16_kernel_rt2<3>". */
@@ -374,7 +382,7 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
 int unetmi_conv2d_b16_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
                           const float* bias, const float* scale, const float* shift, const float* act_param,
                           const float* gate, void* out, void* stream);
-/* unetmi_conv2d_b16_fwd writing plain fp32 NCHW [N,K,OH,OW] (the descriptor's reserved[2] is taken as 1) with an
+/* unetmi_conv2d_b16_fwd writing plain fp32 NCHW [N,K,OH,OW] (UNETMI_B16_OUT_NCHW_F32 is taken as set) with an
  * optional fp32 NCHW tensor of that shape added to the result -- the `y + res` in front of the next block of an
  * additive-skip decoder (ResUNet.py:206-210).  Together with unetmi_blocked_from_nchw_sum it lets a network whose
  * tensors stay fp32 NCHW run single convolutions with bfloat16 operands (ResUNet's strided Encoder / Decoder
@@ -388,20 +396,22 @@ int unetmi_conv2d_b16_nchw_fwd(const UnetmiConvDesc* d, const void* in0, const v
  *   out[p] = head_act(sum_k head_w[p][k] * decoder_out[k] + head_b[p]),   p < head_channels <= 4.
  * head_w [head_channels][K] fp32, head_b [head_channels] or null, head_act = UNETMI_ACT_* (not LeakyReLU, not GELU).
  * out: fp32 [N][head_channels][OH][OW], or with interleaved != 0 [N][OH][OW][head_channels] (two channels that
- * way are a complex64 [N][OH][OW] tensor, which is what the reference's CRM head returns).  The descriptor's
- * reserved[2] is ignored.  Not built for time-stride-2 transposed layers (UNETMI_E_BAD_DESC). */
+ * way are a complex64 [N][OH][OW] tensor, which is what the reference's CRM head returns).  Of the descriptor's
+ * reserved[2] only UNETMI_B16_IN_F16 matters.  Not built for time-stride-2 transposed layers (UNETMI_E_BAD_DESC). */
 int unetmi_conv2d_b16_head_fwd(const UnetmiConvDesc* d, const void* in0, const void* in1, const void* wpacked,
                                const float* bias, const float* scale, const float* shift, const float* act_param,
                                const float* gate, const float* head_w, const float* head_b, int head_channels,
                                int head_act, int interleaved, float* out, void* stream);
-/* Layout conversion either side of such a chain: src NCHW [N,C,HW] (UNETMI_DTYPE_*) -> blocked, and back.
- * These have no counterpart in the reference (its tensors are NCHW throughout). */
+/* Layout conversion either side of such a chain: src NCHW [N,C,HW] (UNETMI_DTYPE_F32 / _BF16) -> blocked bfloat16,
+ * and back.  These have no counterpart in the reference (its tensors are NCHW throughout). */
 int unetmi_blocked_from_nchw(int N, int C, int HW, const void* src, int src_dtype, void* dst, void* stream);
 /* The same with a second tensor of the same shape and storage type added first (src + src2 in fp32, rounded once;
- * src2 may be null): the summed skip in front of a decoder (ResUNet.py:209) costs no pass of its own. */
+ * src2 may be null): the summed skip in front of a decoder (ResUNet.py:209) costs no pass of its own.
+ * dst_dtype: UNETMI_DTYPE_BF16 or UNETMI_DTYPE_F16, the 16-bit format of the blocked tensor. */
 int unetmi_blocked_from_nchw_sum(int N, int C, int HW, const void* src, const void* src2, int src_dtype, void* dst,
-                                 void* stream);
-int unetmi_nchw_from_blocked(int N, int C, int HW, const void* src, void* dst, int dst_dtype, void* stream);
+                                 int dst_dtype, void* stream);
+/* src_dtype: UNETMI_DTYPE_BF16 or UNETMI_DTYPE_F16 (the blocked tensor); dst_dtype: UNETMI_DTYPE_F32 or _BF16 (NCHW). */
+int unetmi_nchw_from_blocked(int N, int C, int HW, const void* src, int src_dtype, void* dst, int dst_dtype, void* stream);
 
 
 /* Complex ratio filter / complex mask application over the STFT:

@@ -28,6 +28,11 @@ def bf(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def rnd(t, fmt):
+    """t rounded to the blocked tensor's 16-bit format"""
+    return t.to(torch.float16 if fmt == "fp16" else torch.bfloat16).to(torch.float32)
+
+
 def test_layout_round_trip(device):
     from unet_amd.blocked import BlockedTensor
     g = torch.Generator().manual_seed(1)
@@ -41,6 +46,13 @@ def test_layout_round_trip(device):
             # padded channels are zero
             flat = b.data.permute(0, 1, 4, 2, 3).reshape(2, -1, 5, 37)
             assert flat[:, C:].abs().max().item() == 0 if flat.shape[1] > C else True
+            # the fp16 form of the layout: same records, three more mantissa bits, saturating at +-65504
+            h = BlockedTensor.from_nchw(src.to(device), fmt="fp16")
+            assert h.data.dtype == torch.float16 and h.fmt == "fp16" and b.fmt == "bf16"
+            assert torch.equal(h.to_nchw(torch.float32).cpu(), src.float().to(torch.float16).float())
+    big = torch.tensor([[[[1e6, -1e6, 65504.0, 70000.0, float("nan")]]]])
+    sat = BlockedTensor.from_nchw(big.to(device), fmt="fp16").to_nchw(torch.float32).cpu()[0, 0, 0]
+    assert sat[:4].tolist() == [65504.0, -65504.0, 65504.0, 65504.0] and torch.isnan(sat[4])
 
 
 CASES = [
@@ -75,12 +87,20 @@ def test_conv_b16_matches_cpu(device, case, halves):
     run_case(device, case, halves, 2)
 
 
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "C{}+{}_K{}_k{}x{}_s{}{}_{}".format(
+    c[0], c[1], c[2], c[3][0], c[3][1], c[4][0], c[4][1], "T" if c[7] else "C"))
+def test_conv_fp16_operands_match_cpu(device, case):
+    """The same layers with fp16 operands (inputs, weight image) and an fp16 blocked output: same kernels on
+    v_mfma_f32_32x32x16_f16, held to the fp16 rounding of the same reference."""
+    run_case(device, case, 1, 2, fmt="fp16")
+
+
 # Shapes large enough for the plan to take the two-rows-per-wave kernels (16-row workgroup tiles; every phase at
 # least 16 rows high and 512 workgroups or more): a (7,1) layer over 135 channels, whose regular plan is a
 # one-column-tile kernel, and a time-stride-2 transposed 7x5 layer with three channel tiles.
 RT2_CASES = [
-    (16, (90, 45, 90, (7, 1), (1, 1), (3, 0), (0, 0), True, 64, 512), "conv_b16_kernel_rt2<3>"),
-    (28, (90, 90, 90, (7, 5), (2, 2), (3, 2), (0, 1), True, 33, 128), "conv_b16_kernel_pair_rt2<3>"),
+    (16, (90, 45, 90, (7, 1), (1, 1), (3, 0), (0, 0), True, 64, 512), "conv_b16_kernel_rt2<3, false>"),
+    (28, (90, 90, 90, (7, 5), (2, 2), (3, 2), (0, 1), True, 33, 128), "conv_b16_kernel_pair_rt2<3, false>"),
 ]
 
 
@@ -93,9 +113,12 @@ def test_conv_b16_two_rows_per_wave(device, N, case, kernel):
     d = b16_desc(N, C0, C1, H, W, geom, int(transposed), _lib.ACT_LEAKY, 0, 0, 1, 1, False)
     assert conv_b16_kernel_name(d) == kernel, "the plan no longer takes the two-row kernel for this shape"
     run_case(device, case, 1, N, with_head=False)
+    d16 = b16_desc(N, C0, C1, H, W, geom, int(transposed), _lib.ACT_LEAKY, 0, 0, 1, 1, False, True, True)
+    assert conv_b16_kernel_name(d16) == kernel.replace("false>", "true>")
+    run_case(device, case, 1, N, with_head=False, fmt="fp16")
 
 
-def run_case(device, case, halves, N, with_head=True):
+def run_case(device, case, halves, N, with_head=True, fmt="bf16"):
     from unet_amd.blocked import BlockedConv, BlockedTensor
     C0, C1, K, k, s, p, op, transposed, H, W = case
     g = torch.Generator().manual_seed(hash(case) % 1000 + halves)
@@ -116,17 +139,18 @@ def run_case(device, case, halves, N, with_head=True):
     x0 = torch.randn(N, C0, H, W, generator=g)
     x1 = torch.randn(N, C1, H, W, generator=g) if C1 else None
     gate = torch.rand(N, K, generator=g) + 0.25
+    ulp = 2.0 ** -11 if fmt == "fp16" else 2.0 ** -8           # one rounding step of the stored output
     with torch.no_grad():
-        xin = bf(x0) if x1 is None else torch.cat([bf(x0), bf(x1)], 1)
+        xin = rnd(x0, fmt) if x1 is None else torch.cat([rnd(x0, fmt), rnd(x1, fmt)], 1)
         ref_conv = conv
         if halves == 1:
             ref_conv = type(conv)(C, K, k, stride=s, padding=p, **(dict(output_padding=op) if transposed else {}))
-            ref_conv.weight.copy_(bf(conv.weight))
+            ref_conv.weight.copy_(rnd(conv.weight, fmt))
             ref_conv.bias.copy_(conv.bias)
         want = act(bn(ref_conv(xin))) * gate[:, :, None, None]
-    layer = BlockedConv(conv, bn, act, halves=halves)
-    b0 = BlockedTensor.from_nchw(x0.to(device))
-    b1 = BlockedTensor.from_nchw(x1.to(device)) if x1 is not None else None
+    layer = BlockedConv(conv, bn, act, halves=halves, out_fmt=fmt)
+    b0 = BlockedTensor.from_nchw(x0.to(device), fmt=fmt)
+    b1 = BlockedTensor.from_nchw(x1.to(device), fmt=fmt) if x1 is not None else None
     try:
         got = layer(b0, b1, gate.to(device))
     except UnetmiError as e:
@@ -136,8 +160,9 @@ def run_case(device, case, halves, N, with_head=True):
     assert got.shape == tuple(want.shape)
     got32 = got.to_nchw(torch.float32).cpu()
     scale = want.abs().max().item()
-    err = (got32 - bf(want)).abs().max().item() / scale
-    assert err <= 2.0 ** -8 + 1e-4, "blocked conv vs rounded reference: {:.3e}".format(err)
+    assert got.fmt == fmt
+    err = (got32 - rnd(want, fmt)).abs().max().item() / scale
+    assert err <= ulp + 1e-4, "blocked conv vs rounded reference: {:.3e}".format(err)
     # the unrounded accumulator path: fp32 NCHW output holds the fp32 bar
     head = BlockedConv(conv, bn, act, halves=halves, nchw_out=True)
     got_f32 = head(b0, b1, gate.to(device)).cpu()
@@ -149,8 +174,8 @@ def run_case(device, case, halves, N, with_head=True):
     e = rel_err(got_res, want + res)
     assert e <= 1e-4, "fp32-output blocked conv + residual: rel-err {:.3e}".format(e)
     xa, xb_ = x0 * 0.25, x0 - x0 * 0.25
-    summed = BlockedTensor.from_nchw(xa.to(device), addend=xb_.to(device))
-    assert torch.equal(summed.data.cpu(), BlockedTensor.from_nchw((xa + xb_).to(device)).data.cpu())
+    summed = BlockedTensor.from_nchw(xa.to(device), addend=xb_.to(device), fmt=fmt)
+    assert torch.equal(summed.data.cpu(), BlockedTensor.from_nchw((xa + xb_).to(device), fmt=fmt).data.cpu())
     # padded output channels are exact zeros (the next layer multiplies them by zero weights)
     raw = got.data.permute(0, 1, 4, 2, 3).reshape(N, -1, *got.data.shape[2:4])
     if raw.shape[1] > K:

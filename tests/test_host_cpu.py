@@ -389,6 +389,34 @@ def test_blocked_conv_folds_only_eval_batchnorm_and_handles_affine_false():
         BlockedConv(conv, untracked, nn.ReLU())._prepare(16, 0, torch.device("cpu"))
 
 
+def test_fp16_weight_image_matches_numpy_rounding():
+    """The fp16 form of the weight image (UNETMI_B16_IN_F16): the same layout with nearest-even fp16 values -- normal,
+    subnormal and tiny magnitudes as numpy rounds them, magnitudes beyond the largest finite fp16 value saturated --
+    and the second half holding the fp16-rounded remainder."""
+    import torch
+    from unet_amd.blocked import pack_b16_weights
+    rng = np.random.default_rng(11)
+    K, C = 32, 16
+    w = rng.standard_normal((K, C, 1, 1)).astype(np.float32)
+    w[0, :, 0, 0] = np.float32(2.0) ** -np.arange(10, 26)                  # down into the subnormals and below them
+    w[1, :, 0, 0] = (1.0 + 2.0 ** -11) * np.float32(2.0) ** np.arange(-8, 8)   # ties: to even
+    w[2, :4, 0, 0] = [65504.0, 65519.9, 65520.0, -1e9]
+    w[3, :3, 0, 0] = [6.0e-8, 2.9e-8, 3.1e-8]
+    img = pack_b16_weights(torch.from_numpy(w), C, 0, [K, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0], 0, halves=2, f16=True).numpy().view(np.uint16)
+    img = img.reshape(1, 2, 1, 2, 32, 8)                                   # [group][weight half][tile][k half][row][k]
+    with np.errstate(over="ignore"):
+        hi = w.astype(np.float16)
+    hi = np.where(np.isinf(hi), np.sign(w).astype(np.float16) * np.float16(65504), hi)
+    with np.errstate(over="ignore"):
+        lo = (w - hi.astype(np.float32)).astype(np.float16)
+    for co in range(K):
+        for ci in range(C):
+            got = img[0, :, 0, ci // 8, co, ci % 8]
+            assert got[0] == hi[co, ci, 0, 0].view(np.uint16), (co, ci, w[co, ci, 0, 0])
+            if np.isfinite(lo[co, ci, 0, 0]) and abs(w[co, ci, 0, 0]) < 65520:
+                assert got[1] == lo[co, ci, 0, 0].view(np.uint16), (co, ci)
+
+
 def test_bf16_plan_takes_two_row_kernels_where_they_pay():
     """Host logic only (unetmi_conv2d_b16_kernel_name launches nothing).  DSUNet's benchmark shapes at batch 32: the
     (7,1) last decoder over 135 channels and the stride-(2,2) 7x5 decoder take the two-rows-per-wave kernels, the
@@ -397,16 +425,19 @@ def test_bf16_plan_takes_two_row_kernels_where_they_pay():
     from unet_amd import _lib
     from unet_amd.ops import b16_desc, conv_b16_kernel_name
 
-    def name(N, C0, C1, H, W, geom, head=0):
-        return conv_b16_kernel_name(b16_desc(N, C0, C1, H, W, geom, 1, _lib.ACT_LEAKY, 0, 0, 0, 1, False), head)
+    def name(N, C0, C1, H, W, geom, head=0, f16=False):
+        return conv_b16_kernel_name(b16_desc(N, C0, C1, H, W, geom, 1, _lib.ACT_LEAKY, 0, 0, 0, 1, False, f16, f16), head)
 
     dec9, dec8 = [90, 7, 1, 1, 1, 3, 0, 1, 1, 0, 0], [90, 1, 7, 1, 1, 0, 3, 1, 1, 0, 0]
     dec7 = [90, 7, 5, 2, 2, 3, 2, 1, 1, 0, 1]
-    assert name(32, 90, 45, 257, 512, dec9) == "conv_b16_kernel_rt2<3>"
-    assert name(32, 90, 45, 257, 512, dec9, head=2) == "conv_b16_kernel_occ2<3, 1>"
-    assert name(32, 90, 45, 257, 512, dec8) == "conv_b16_kernel_occ2<3, 2>"
-    assert name(32, 90, 90, 129, 256, dec7) == "conv_b16_kernel_pair_rt2<3>"
-    assert name(2, 90, 90, 33, 128, dec7) == "conv_b16_kernel_pair_occ2<3>"
+    assert name(32, 90, 45, 257, 512, dec9) == "conv_b16_kernel_rt2<3, false>"
+    assert name(32, 90, 45, 257, 512, dec9, head=2) == "conv_b16_kernel_occ2<3, 1, false>"
+    assert name(32, 90, 45, 257, 512, dec8) == "conv_b16_kernel_occ2<3, 2, false>"
+    assert name(32, 90, 90, 129, 256, dec7) == "conv_b16_kernel_pair_rt2<3, false>"
+    assert name(2, 90, 90, 33, 128, dec7) == "conv_b16_kernel_pair_occ2<3, false>"
+    # fp16 operands: the same plan, the instantiations on the fp16 matrix instruction
+    assert name(32, 90, 45, 257, 512, dec9, head=2, f16=True) == "conv_b16_kernel_occ2<3, 1, true>"
+    assert name(32, 90, 90, 129, 256, dec7, f16=True) == "conv_b16_kernel_pair_rt2<3, true>"
     with pytest.raises(_lib.UnetmiError, match="time-stride-2"):
         name(32, 90, 90, 129, 256, dec7, head=2)
 

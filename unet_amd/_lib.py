@@ -21,7 +21,8 @@ if os.environ.get("UNETMI_LIBRARY"):
 # activation / input-mode codes of include/unetmi.h
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SILU, ACT_SOFTPLUS, ACT_SIGMOID, ACT_TANH, ACT_GELU = range(8)
 IN_SINGLE, IN_CONCAT, IN_ADD = range(3)
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+B16_OUT_NCHW_F32, B16_IN_F16, B16_OUT_F16 = 1, 2, 4      # bits of UnetmiConvDesc.reserved[2] for the 16-bit convolution
 
 EXPORTED_SYMBOLS = (
     "unetmi_version",
@@ -184,13 +185,13 @@ def _load():
     lib.unetmi_conv2d_b16_fwd.restype = ctypes.c_int
     lib.unetmi_conv2d_b16_nchw_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 10 + [vp]
     lib.unetmi_conv2d_b16_nchw_fwd.restype = ctypes.c_int
-    lib.unetmi_blocked_from_nchw_sum.argtypes = [ci] * 3 + [fp, fp, ci, fp, vp]
+    lib.unetmi_blocked_from_nchw_sum.argtypes = [ci] * 3 + [fp, fp, ci, fp, ci, vp]
     lib.unetmi_blocked_from_nchw_sum.restype = ctypes.c_int
     lib.unetmi_conv2d_b16_head_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [fp] * 10 + [ci] * 3 + [fp, vp]
     lib.unetmi_conv2d_b16_head_fwd.restype = ctypes.c_int
     lib.unetmi_blocked_from_nchw.argtypes = [ci] * 3 + [fp, ci, fp, vp]
     lib.unetmi_blocked_from_nchw.restype = ctypes.c_int
-    lib.unetmi_nchw_from_blocked.argtypes = [ci] * 3 + [fp, fp, ci, vp]
+    lib.unetmi_nchw_from_blocked.argtypes = [ci] * 3 + [fp, ci, fp, ci, vp]
     lib.unetmi_nchw_from_blocked.restype = ctypes.c_int
     lib.unetmi_bn_running_update.argtypes = [ci, ll, cf, cf, fp, fp, fp, fp, vp]
     lib.unetmi_bn_running_update.restype = ctypes.c_int

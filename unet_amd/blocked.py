@@ -1,7 +1,9 @@
-"""bfloat16-operand convolution chain on the channel-blocked layout (csrc/conv_b16.hip).
+"""16-bit-operand convolution chain on the channel-blocked layout (csrc/conv_b16.hip).
 
-``BlockedTensor`` carries an activation as ``[N, CB, H, W, 8]`` bfloat16 (CB = 2 * ceil(C / 16), padded
-channels are zero) together with its logical channel count.  ``BlockedConv`` is the blocked-layout
+``BlockedTensor`` carries an activation as ``[N, CB, H, W, 8]`` bfloat16 or float16 (CB = 2 * ceil(C / 16), padded
+channels are zero; the tensor's dtype names the format) together with its logical channel count.  A layer's operand
+format is its input's: fp16 has three more mantissa bits at the same matrix rate and suits activations of modest
+range (behind a BatchNorm); bfloat16 suits a network input of unknown scale.  ``BlockedConv`` is the blocked-layout
 counterpart of ``fused.FusedConv``: conv / transposed conv + eval BatchNorm + activation (+ gate, + the
 concat with a skip tensor) as one launch of the bf16 MFMA kernel.
 """
@@ -33,12 +35,18 @@ class BlockedTensor:
         return (N, self.C, H, W)
 
     @staticmethod
-    def from_nchw(x, addend=None):
+    def from_nchw(x, addend=None, fmt="bf16"):
         """x: contiguous fp32 or bfloat16 device tensor [N,C,H,W]; ``addend`` (same shape and type) is added first
-        (in fp32, one rounding)."""
-        if addend is None:
+        (in fp32, one rounding); ``fmt``: "bf16" or "fp16", the blocked tensor's 16-bit format."""
+        if fmt not in ("bf16", "fp16"):
+            raise ValueError("BlockedTensor.from_nchw: fmt is 'bf16' or 'fp16'")
+        if addend is None and fmt == "bf16":
             return BlockedTensor(_ops.blocked_from_nchw(x), x.shape[1])
-        return BlockedTensor(_ops.blocked_from_nchw_sum(x, addend), x.shape[1])
+        return BlockedTensor(_ops.blocked_from_nchw_sum(x, addend, fmt == "fp16"), x.shape[1])
+
+    @property
+    def fmt(self):
+        return "fp16" if self.data.dtype == torch.float16 else "bf16"
 
     def to_nchw(self, dtype=torch.bfloat16):
         if dtype not in (torch.bfloat16, torch.float32):
@@ -59,8 +67,8 @@ def _geom_of(conv):
 _desc = _ops.b16_desc
 
 
-def pack_b16_weights(weight, C0, C1, geom, transposed, halves=1):
-    d = _desc(1, C0, C1, 64, 64, geom, transposed, 0, 0, 0, 0, halves, False)
+def pack_b16_weights(weight, C0, C1, geom, transposed, halves=1, f16=False):
+    d = _desc(1, C0, C1, 64, 64, geom, transposed, 0, 0, 0, 0, halves, False, f16, False)
     nbytes = _lib.lib.unetmi_conv2d_b16_packed_weight_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise _lib.UnetmiError("conv2d_b16_packed_weight_bytes: " + _lib.last_error(), _lib.E_BAD_DESC)
@@ -72,12 +80,12 @@ def pack_b16_weights(weight, C0, C1, geom, transposed, halves=1):
 
 
 def conv2d_b16(x, skip, wpacked, bias, scale, shift, act_param, gate, geom, transposed, act, act_first=0,
-               halves=1, nchw_out=False):
+               halves=1, nchw_out=False, out_f16=False):
     """One launch (torch.ops.unetmi.conv2d_b16_fwd).  x, skip: BlockedTensor (skip may be None); returns a
-    BlockedTensor, or with ``nchw_out`` a plain fp32 [N,K,OH,OW] tensor."""
+    BlockedTensor (fp16 with ``out_f16``, else bfloat16), or with ``nchw_out`` a plain fp32 [N,K,OH,OW] tensor."""
     out = _ops.conv2d_b16_fwd(x.data, x.C, None if skip is None else skip.data, 0 if skip is None else skip.C, wpacked,
                               bias, scale, shift, act_param, gate, list(geom),
-                              [int(transposed), int(act), int(act_first), int(halves), int(nchw_out)])
+                              [int(transposed), int(act), int(act_first), int(halves), int(nchw_out), int(out_f16)])
     return out if nchw_out else BlockedTensor(out, geom[0])
 
 
@@ -85,7 +93,11 @@ class BlockedConv:
     """conv [+ BatchNorm2d(eval)] [+ activation] on blocked tensors; parameters are folded and packed on
     first use for the channel split (C0, C1) it is called with, and again when a parameter changes."""
 
-    def __init__(self, conv, norm=None, act=None, halves=1, nchw_out=False):
+    def __init__(self, conv, norm=None, act=None, halves=1, nchw_out=False, out_fmt="bf16"):
+        """``out_fmt``: "bf16" or "fp16", the format of the blocked output (the operands' format is the input's)."""
+        if out_fmt not in ("bf16", "fp16"):
+            raise ValueError("BlockedConv: out_fmt is 'bf16' or 'fp16'")
+        self.out_f16 = out_fmt == "fp16"
         if norm is not None and not isinstance(norm, (nn.BatchNorm2d, nn.Identity)):
             raise ValueError("BlockedConv: only BatchNorm2d (eval) can be folded")
         code = activation_code(act)
@@ -106,12 +118,12 @@ class BlockedConv:
             ts.append(self.act_src)
         return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
 
-    def _prepare(self, C0, C1, device):
+    def _prepare(self, C0, C1, device, f16=False):
         key = (self._versions(), str(device), self.norm is not None and self.norm.training)
         if key != self._key:
             self._img.clear()
             self._key = key
-        st = self._img.get((C0, C1))
+        st = self._img.get((C0, C1, f16))
         if st is not None:
             return st
         K = self.geom[0]
@@ -136,14 +148,16 @@ class BlockedConv:
             ap = torch.tensor([float(self.act_src)], **f32)
         else:
             ap = torch.zeros(1, **f32) if self.act_code == _lib.ACT_LEAKY else None
-        st = dict(w=pack_b16_weights(self.conv.weight, C0, C1, self.geom, self.transposed, self.halves).to(device),
+        st = dict(w=pack_b16_weights(self.conv.weight, C0, C1, self.geom, self.transposed, self.halves, f16).to(device),
                   bias=bias.contiguous(), scale=scale.contiguous(), shift=shift.contiguous(), ap=ap)
-        self._img[(C0, C1)] = st
+        self._img[(C0, C1, f16)] = st
         return st
 
     def __call__(self, x, skip=None, gate=None, residual=None):
         """``residual`` (fp32 NCHW, shaped like the output; with ``nchw_out`` only) is added to the result."""
-        st = self._prepare(x.C, 0 if skip is None else skip.C, x.data.device)
+        if skip is not None and skip.data.dtype != x.data.dtype:
+            raise ValueError("BlockedConv: the two inputs of a layer share one 16-bit format")
+        st = self._prepare(x.C, 0 if skip is None else skip.C, x.data.device, x.data.dtype == torch.float16)
         if residual is not None:
             if not self.nchw_out:
                 raise ValueError("BlockedConv: a residual goes with the fp32 NCHW output")
@@ -151,13 +165,15 @@ class BlockedConv:
                                             st["w"], st["bias"], st["scale"], st["shift"], st["ap"], gate, residual,
                                             list(self.geom), [int(self.transposed), int(self.act_code), 0, int(self.halves)])
         return conv2d_b16(x, skip, st["w"], st["bias"], st["scale"], st["shift"], st["ap"], gate, self.geom,
-                          self.transposed, self.act_code, 0, self.halves, self.nchw_out)
+                          self.transposed, self.act_code, 0, self.halves, self.nchw_out, self.out_f16)
 
     def with_head(self, x, skip, head_conv, head_act_code, interleaved=True, gate=None):
         """This layer followed by the 1x1 convolution ``head_conv`` (at most four output channels) and its
         activation as ONE launch: the layer's output stays in the fp32 accumulators and only the head's result is
         written -- fp32 [N, OH, OW, P] (``interleaved``; two channels are a complex64 tensor) or [N, P, OH, OW]."""
-        st = self._prepare(x.C, 0 if skip is None else skip.C, x.data.device)
+        if skip is not None and skip.data.dtype != x.data.dtype:
+            raise ValueError("BlockedConv: the two inputs of a layer share one 16-bit format")
+        st = self._prepare(x.C, 0 if skip is None else skip.C, x.data.device, x.data.dtype == torch.float16)
         # the head's parameters are used as they are (views when they already are fp32 tensors on the device)
         P = head_conv.out_channels
         head_w = head_conv.weight.detach().to(dtype=torch.float32, device=x.data.device).reshape(P, -1).contiguous()

@@ -47,8 +47,28 @@ typedef float b16_f32x2 __attribute__((ext_vector_type(2)));
 typedef float b16_f32x4 __attribute__((ext_vector_type(4)));
 typedef float b16_f32x4_u __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte access at element alignment
 
+typedef _Float16 b16_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 b16_f16x8 __attribute__((ext_vector_type(8)));
+
 __device__ __forceinline__ unsigned b16_pack2(float lo, float hi) {        // v_cvt_pk_bf16_f32: nearest-even
     return __builtin_bit_cast(unsigned, __builtin_convertvector(b16_f32x2{lo, hi}, b16_bf16x2));
+}
+// two fp16 values, nearest-even, saturating at the largest finite value (a NaN stays a NaN)
+__device__ __forceinline__ float b16_sat_f16(float v) { return v != v ? v : fminf(fmaxf(v, -65504.f), 65504.f); }
+__device__ __forceinline__ unsigned b16_pack2_f16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(b16_f32x2{b16_sat_f16(lo), b16_sat_f16(hi)}, b16_f16x2));
+}
+// the 16-bit storage format of a blocked tensor is a run-time property of the layer's OUTPUT
+__device__ __forceinline__ unsigned b16_pack2_as(float lo, float hi, int f16) {
+    return f16 ? b16_pack2_f16(lo, hi) : b16_pack2(lo, hi);
+}
+// ... and a compile-time property of its OPERANDS (both inputs and the weight image): same matrix rate either way
+template <bool F16>
+__device__ __forceinline__ b16_f32x16 b16_mfma(bf16x8 a, bf16x8 b, b16_f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(b16_f16x8, a), __builtin_bit_cast(b16_f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 #ifndef B16_ABLATE
@@ -84,6 +104,7 @@ struct B16Args {
     int pair;                // 1: column tiles = the two column phases
     int in_buf_bytes, w_buf_bytes;
     int act, act_first, act_pc, out_nchw_f32;
+    int out_f16;             // blocked output stored as fp16 instead of bfloat16
     // fused 1x1 head: out = head_act(head_w [P][K] . layer_output + head_b) per pixel, written as fp32 instead of the
     // layer's own output (head_P = 0: no head).  head_il: [N][OH][OW][P] instead of [N][P][OH][OW].
     const float* residual;   // out_nchw_f32 only: fp32 [N,K,OH,OW] added to the result, or null
@@ -274,8 +295,8 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
                 // lanes l and l+32 hold the two halves of a pixel's record in each column tile: swapping the upper
                 // lanes of tile 0 with the lower lanes of tile 1 leaves every lane with one whole 16-byte record
                 // (lanes 0..31: tile 0, lanes 32..63: tile 1)
-                unsigned lo0 = b16_pack2(v[0][0], v[0][1]), lo1 = b16_pack2(v[1][0], v[1][1]);
-                unsigned hi0 = b16_pack2(v[0][2], v[0][3]), hi1 = b16_pack2(v[1][2], v[1][3]);
+                unsigned lo0 = b16_pack2_as(v[0][0], v[0][1], p.out_f16), lo1 = b16_pack2_as(v[1][0], v[1][1], p.out_f16);
+                unsigned hi0 = b16_pack2_as(v[0][2], v[0][3], p.out_f16), hi1 = b16_pack2_as(v[1][2], v[1][3], p.out_f16);
                 swap_lane_halves(lo0, lo1);
                 swap_lane_halves(hi0, hi1);
                 if ((half ? ok[1] : ok[0]) && blk < CBo) {
@@ -284,8 +305,8 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
                 }
             } else if (ok[0] && blk < CBo) {
                 uint2 w2;
-                w2.x = b16_pack2(v[0][0], v[0][1]);
-                w2.y = b16_pack2(v[0][2], v[0][3]);
+                w2.x = b16_pack2_as(v[0][0], v[0][1], p.out_f16);
+                w2.y = b16_pack2_as(v[0][2], v[0][3], p.out_f16);
                 char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + pix[0]) * 16 + half * 8;
                 *reinterpret_cast<uint2*>(o) = w2;
             }
@@ -376,7 +397,7 @@ __device__ __forceinline__ void b16_head_epilogue(const b16_f32x16 (&acc)[MT][NT
 // accumulator tiles, so a tap's MT weight operands serve RT*NT pixel operands (MT = 3, NT = 2: 7 LDS reads per 12
 // MFMAs instead of 5 per 6 -- 0.58 KB of LDS reads per MFMA against a budget of 1 KB at the matrix peak) and the
 // input rows of the taps' halo are shared by twice as many output rows.  One workgroup per CU (192 accumulators).
-template <int MT, int NT, bool GEN, bool OCC2, bool PAIR, int RT = 1>
+template <int MT, int NT, bool GEN, bool OCC2, bool PAIR, int RT = 1, bool F16 = false>
 __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     static_assert(!PAIR || NT == 2, "pair mode uses both column tiles");
     static_assert(RT == 1 || (!OCC2 && !GEN && NT == 2), "two rows per wave: the one-workgroup-per-CU two-tile kernels only");
@@ -589,7 +610,7 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
                                 __builtin_amdgcn_sched_barrier(0);      // the read goes out BEFORE the MFMAs it hides under
 #pragma unroll
                                 for (int rt = 0; rt < RT; ++rt)
-                                    acc[rt][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur], B[rt], acc[rt][mt][nt], 0, 0, 0);
+                                    acc[rt][mt][nt] = b16_mfma<F16>(A[cur], B[rt], acc[rt][mt][nt]);
                             }
                             uw = b16_keep_scalar(uw + MT * 1024);
                             ub = b16_keep_scalar(ub + tdw16);
@@ -634,7 +655,7 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
                             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                                 for (int nt = 0; nt < NT; ++nt)
-                                    acc[rt][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur], B[rt][nt], acc[rt][mt][nt], 0, 0, 0);
+                                    acc[rt][mt][nt] = b16_mfma<F16>(A[cur], B[rt][nt], acc[rt][mt][nt]);
                         }
                         if (more) {
 #pragma unroll
@@ -693,31 +714,33 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     });
 }
 
-template <int MT, int NT, bool GEN>
-__global__ __launch_bounds__(512, 2) void conv_b16_kernel(const B16Args p) { conv_b16_body<MT, NT, GEN, false, false>(p); }
+// F16: the operands (activations and weight image) are fp16 instead of bfloat16
+template <int MT, int NT, bool GEN, bool F16>
+__global__ __launch_bounds__(512, 2) void conv_b16_kernel(const B16Args p) { conv_b16_body<MT, NT, GEN, false, false, 1, F16>(p); }
 
-template <int MT, int NT>
-__global__ __launch_bounds__(512, 4) void conv_b16_kernel_occ2(const B16Args p) { conv_b16_body<MT, NT, false, true, false>(p); }
+template <int MT, int NT, bool F16>
+__global__ __launch_bounds__(512, 4) void conv_b16_kernel_occ2(const B16Args p) { conv_b16_body<MT, NT, false, true, false, 1, F16>(p); }
 
-template <int MT>
-__global__ __launch_bounds__(512, 2) void conv_b16_kernel_pair(const B16Args p) { conv_b16_body<MT, 2, false, false, true>(p); }
+template <int MT, bool F16>
+__global__ __launch_bounds__(512, 2) void conv_b16_kernel_pair(const B16Args p) { conv_b16_body<MT, 2, false, false, true, 1, F16>(p); }
 
-template <int MT>
-__global__ __launch_bounds__(512, 4) void conv_b16_kernel_pair_occ2(const B16Args p) { conv_b16_body<MT, 2, false, true, true>(p); }
+template <int MT, bool F16>
+__global__ __launch_bounds__(512, 4) void conv_b16_kernel_pair_occ2(const B16Args p) { conv_b16_body<MT, 2, false, true, true, 1, F16>(p); }
 
 // two output rows per wave (16-row workgroup tiles), two column tiles / the two column phases
-template <int MT>
-__global__ __launch_bounds__(512, 2) void conv_b16_kernel_rt2(const B16Args p) { conv_b16_body<MT, 2, false, false, false, 2>(p); }
+template <int MT, bool F16>
+__global__ __launch_bounds__(512, 2) void conv_b16_kernel_rt2(const B16Args p) { conv_b16_body<MT, 2, false, false, false, 2, F16>(p); }
 
-template <int MT>
-__global__ __launch_bounds__(512, 2) void conv_b16_kernel_pair_rt2(const B16Args p) { conv_b16_body<MT, 2, false, false, true, 2>(p); }
+template <int MT, bool F16>
+__global__ __launch_bounds__(512, 2) void conv_b16_kernel_pair_rt2(const B16Args p) { conv_b16_body<MT, 2, false, false, true, 2, F16>(p); }
 
 // ---- layout conversion ------------------------------------------------------------------------
 // NCHW (fp32 or bfloat16) -> blocked; a thread owns one pixel of one 8-channel block.
 // A thread owns FOUR consecutive pixels of one 8-channel block: per channel one 16-byte (fp32) or 8-byte (bfloat16)
 // load -- element alignment is enough for them -- and four 16-byte records out (64 contiguous bytes per thread).
 template <bool SRC_BF16>
-__global__ __launch_bounds__(256) void to_blocked_kernel(const void* src, const void* src2, char* dst, int C, int CB, int HW) {
+__global__ __launch_bounds__(256) void to_blocked_kernel(const void* src, const void* src2, char* dst, int C, int CB, int HW,
+                                                         int dst_f16) {
     const int pix = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int blk = blockIdx.y, n = blockIdx.z;
     if (pix >= HW) return;
@@ -762,14 +785,14 @@ __global__ __launch_bounds__(256) void to_blocked_kernel(const void* src, const 
     for (int q = 0; q < 4; ++q) {
         if (q >= np) break;
         uint4 r;
-        r.x = b16_pack2(f[0][q], f[1][q]); r.y = b16_pack2(f[2][q], f[3][q]);
-        r.z = b16_pack2(f[4][q], f[5][q]); r.w = b16_pack2(f[6][q], f[7][q]);
+        r.x = b16_pack2_as(f[0][q], f[1][q], dst_f16); r.y = b16_pack2_as(f[2][q], f[3][q], dst_f16);
+        r.z = b16_pack2_as(f[4][q], f[5][q], dst_f16); r.w = b16_pack2_as(f[6][q], f[7][q], dst_f16);
         *reinterpret_cast<uint4*>(o + q * 16) = r;
     }
 }
 
 template <bool DST_BF16>
-__global__ __launch_bounds__(256) void from_blocked_kernel(const char* src, void* dst, int C, int CB, int HW) {
+__global__ __launch_bounds__(256) void from_blocked_kernel(const char* src, void* dst, int C, int CB, int HW, int src_f16) {
     const int pix = blockIdx.x * 256 + threadIdx.x;
     const int blk = blockIdx.y, n = blockIdx.z;
     if (pix >= HW) return;
@@ -780,7 +803,8 @@ __global__ __launch_bounds__(256) void from_blocked_kernel(const char* src, void
         const int c = blk * 8 + k;
         if (c >= C) continue;
         const unsigned short b = (unsigned short)(k & 1 ? w[k >> 1] >> 16 : w[k >> 1] & 0xffffu);
-        st_act<DST_BF16>(dst, ((size_t)n * C + c) * HW + pix, bf16_bits_to_f32(b));
+        const float v = src_f16 ? (float)__builtin_bit_cast(_Float16, b) : bf16_bits_to_f32(b);
+        st_act<DST_BF16>(dst, ((size_t)n * C + c) * HW + pix, v);
     }
 }
 
@@ -805,6 +829,40 @@ static unsigned short host_bf16(float v) {
 static float host_bf16_to_f32(unsigned short b) {
     const unsigned u = (unsigned)b << 16;
     float v;
+    std::memcpy(&v, &u, 4);
+    return v;
+}
+
+// fp32 -> fp16 bits, nearest-even, saturating at the largest finite value (what the device's conversion does)
+static unsigned short host_f16(float v) {
+    unsigned u;
+    std::memcpy(&u, &v, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    const unsigned mag = u & 0x7fffffffu;
+    if (mag > 0x7f800000u) return (unsigned short)(sign | 0x7e00u);            // NaN
+    if (mag >= 0x477ff000u) return (unsigned short)(sign | 0x7bffu);           // >= 65520 rounds past 65504: saturate
+    if (mag < 0x33000001u) return (unsigned short)sign;                        // below half the smallest subnormal
+    int e = (int)(mag >> 23) - 127;
+    unsigned m = (mag & 0x7fffffu) | 0x800000u;                                // 24-bit significand
+    int shift = e < -14 ? 13 + (-14 - e) : 13;                                  // bits dropped (subnormals drop more)
+    unsigned half = m >> shift;
+    const unsigned rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+    if (rem > mid || (rem == mid && (half & 1u))) ++half;
+    // half holds the significand with its hidden bit (normal) or without (subnormal); a carry moves into the exponent
+    const unsigned bits = e < -14 ? half : ((unsigned)(e + 15 - 1) << 10) + half;
+    return (unsigned short)(sign | bits);
+}
+static float host_f16_to_f32(unsigned short h) {
+    const unsigned sign = (unsigned)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 0x1f;
+    const unsigned m = h & 0x3ffu;
+    float v;
+    if (e == 0) v = std::ldexp((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp((float)(m | 0x400u), e - 25);
+    unsigned u;
+    std::memcpy(&u, &v, 4);
+    u |= sign;
     std::memcpy(&v, &u, 4);
     return v;
 }
@@ -834,7 +892,10 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     a.N = d.N; a.H = d.H; a.W = d.W; a.OH = OH; a.OW = OW; a.K = d.K;
     a.G0 = (d.C0 + 15) / 16; a.G1 = (d.C1 + 15) / 16;
     a.hl = hl;
-    a.act = d.act; a.act_first = d.act_first; a.act_pc = d.act_param_per_channel; a.out_nchw_f32 = d.reserved[2] != 0;
+    a.act = d.act; a.act_first = d.act_first; a.act_pc = d.act_param_per_channel; a.out_nchw_f32 = (d.reserved[2] & UNETMI_B16_OUT_NCHW_F32) != 0;
+    a.out_f16 = (d.reserved[2] & UNETMI_B16_OUT_F16) != 0;
+    if (d.reserved[2] & ~(UNETMI_B16_OUT_NCHW_F32 | UNETMI_B16_IN_F16 | UNETMI_B16_OUT_F16))
+        return bad("conv2d_b16: unknown bits in reserved[2]");
     pl->MT = (d.K + 31) / 32;
     if (pl->MT > 4) return bad("conv2d_b16: more than 128 output channels");
     if ((size_t)2 * std::max(a.G0, a.G1) * d.H * d.W * 16 >= (size_t)1 << 31) return bad("conv2d_b16: sample larger than 2 GB");
@@ -1034,10 +1095,11 @@ int unetmi_conv2d_b16_kernel_name(const UnetmiConvDesc* d, int head_channels, ch
     const bool gen = d->act != UNETMI_ACT_NONE && d->act != UNETMI_ACT_LEAKY && d->act != UNETMI_ACT_RELU;
     std::string name;
     const std::string mt = std::to_string(pl.MT), nt = std::to_string(pl.NT);
-    if (pl.RT == 2) name = std::string(pl.args.pair ? "conv_b16_kernel_pair_rt2<" : "conv_b16_kernel_rt2<") + mt + ">";
-    else if (pl.args.pair) name = std::string(pl.occ2 ? "conv_b16_kernel_pair_occ2<" : "conv_b16_kernel_pair<") + mt + ">";
-    else if (pl.occ2) name = "conv_b16_kernel_occ2<" + mt + ", " + nt + ">";
-    else name = "conv_b16_kernel<" + mt + ", " + nt + ", " + (gen ? "true" : "false") + ">";
+    const std::string f16 = (d->reserved[2] & UNETMI_B16_IN_F16) ? ", true>" : ", false>";     // operands fp16 / bfloat16
+    if (pl.RT == 2) name = std::string(pl.args.pair ? "conv_b16_kernel_pair_rt2<" : "conv_b16_kernel_rt2<") + mt + f16;
+    else if (pl.args.pair) name = std::string(pl.occ2 ? "conv_b16_kernel_pair_occ2<" : "conv_b16_kernel_pair<") + mt + f16;
+    else if (pl.occ2) name = "conv_b16_kernel_occ2<" + mt + ", " + nt + f16;
+    else name = "conv_b16_kernel<" + mt + ", " + nt + ", " + (gen ? "true" : "false") + f16;
     std::snprintf(buf, n, "%s", name.c_str());
     return UNETMI_OK;
 }
@@ -1050,6 +1112,7 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
     const B16Args& a = pl.args;
     std::memset(packed, 0, pl.packed_bytes);
     const int C = d->C0 + d->C1, K = d->K, KH = d->kh, KW = d->kw, G = a.G0 + a.G1, MT = pl.MT;
+    const bool f16 = (d->reserved[2] & UNETMI_B16_IN_F16) != 0;
     for (int q = 0; q < a.nphase; ++q) {
         const B16Phase& p = a.ph[q];
         unsigned short* img = reinterpret_cast<unsigned short*>(static_cast<char*>(packed) + p.w_off);
@@ -1073,8 +1136,13 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
                                             if (ci < 0 || co >= K) continue;
                                             const size_t src = d->transposed ? (((size_t)ci * K + co) * KH + ky) * KW + kx
                                                                              : (((size_t)co * C + ci) * KH + ky) * KW + kx;
-                                            const unsigned short hi = host_bf16(w[src]);
-                                            img[dst] = h == 0 ? hi : host_bf16(w[src] - host_bf16_to_f32(hi));
+                                            if (f16) {
+                                                const unsigned short hi = host_f16(w[src]);
+                                                img[dst] = h == 0 ? hi : host_f16(w[src] - host_f16_to_f32(hi));
+                                            } else {
+                                                const unsigned short hi = host_bf16(w[src]);
+                                                img[dst] = h == 0 ? hi : host_bf16(w[src] - host_bf16_to_f32(hi));
+                                            }
                                         }
                     }
     }
@@ -1106,29 +1174,34 @@ static int conv2d_b16_launch(const UnetmiConvDesc* d, const void* in0, const voi
     if (gen && (pl.MT > 1 || pl.args.pair))
         return api_fail(UNETMI_E_UNSUPPORTED, "conv2d_b16: SiLU / Softplus / Sigmoid / Tanh / GELU epilogues are built for K <= 32 "
                                               "and not for time-stride-2 transposed layers");
-#define UNETMI_B16_RT2(MT_)                                                                                 \
-    if (pl.RT == 2 && !pl.args.pair && pl.MT == MT_) {                                                      \
-        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_rt2<MT_>, &raised, pl, st); }           \
-    if (pl.RT == 2 && pl.args.pair && pl.MT == MT_) {                                                       \
-        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair_rt2<MT_>, &raised, pl, st); }
-#define UNETMI_B16(MT_, NT_, GEN_)                                                                          \
-    if (pl.RT == 1 && !pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && gen == GEN_ && !pl.occ2) {           \
-        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel<MT_, NT_, GEN_>, &raised, pl, st); }
-#define UNETMI_B16_OCC2(MT_, NT_)                                                                           \
-    if (pl.RT == 1 && !pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && !gen && pl.occ2) {                   \
-        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_occ2<MT_, NT_>, &raised, pl, st); }
-#define UNETMI_B16_PAIR(MT_)                                                                                \
-    if (pl.RT == 1 && pl.args.pair && pl.MT == MT_ && !pl.occ2) {                                           \
-        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair<MT_>, &raised, pl, st); }          \
-    if (pl.RT == 1 && pl.args.pair && pl.MT == MT_ && pl.occ2) {                                            \
-        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair_occ2<MT_>, &raised, pl, st); }
-    UNETMI_B16(1, 1, false) UNETMI_B16(1, 2, false) UNETMI_B16(2, 1, false) UNETMI_B16(2, 2, false)
-    UNETMI_B16(3, 1, false) UNETMI_B16(3, 2, false) UNETMI_B16(4, 1, false)
-    UNETMI_B16(1, 1, true) UNETMI_B16(1, 2, true)
-    UNETMI_B16_OCC2(1, 1) UNETMI_B16_OCC2(1, 2) UNETMI_B16_OCC2(2, 1) UNETMI_B16_OCC2(2, 2)
-    UNETMI_B16_OCC2(3, 1) UNETMI_B16_OCC2(3, 2) UNETMI_B16_OCC2(4, 1)
-    UNETMI_B16_PAIR(1) UNETMI_B16_PAIR(2) UNETMI_B16_PAIR(3)
-    UNETMI_B16_RT2(1) UNETMI_B16_RT2(2) UNETMI_B16_RT2(3)
+    const bool f16 = (d->reserved[2] & UNETMI_B16_IN_F16) != 0;
+#define UNETMI_B16_RT2(MT_, F_)                                                                             \
+    if (pl.RT == 2 && !pl.args.pair && pl.MT == MT_ && f16 == F_) {                                         \
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_rt2<MT_, F_>, &raised, pl, st); }       \
+    if (pl.RT == 2 && pl.args.pair && pl.MT == MT_ && f16 == F_) {                                          \
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair_rt2<MT_, F_>, &raised, pl, st); }
+#define UNETMI_B16(MT_, NT_, GEN_, F_)                                                                      \
+    if (pl.RT == 1 && !pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && gen == GEN_ && !pl.occ2 && f16 == F_) { \
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel<MT_, NT_, GEN_, F_>, &raised, pl, st); }
+#define UNETMI_B16_OCC2(MT_, NT_, F_)                                                                       \
+    if (pl.RT == 1 && !pl.args.pair && pl.MT == MT_ && pl.NT == NT_ && !gen && pl.occ2 && f16 == F_) {      \
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_occ2<MT_, NT_, F_>, &raised, pl, st); }
+#define UNETMI_B16_PAIR(MT_, F_)                                                                            \
+    if (pl.RT == 1 && pl.args.pair && pl.MT == MT_ && !pl.occ2 && f16 == F_) {                              \
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair<MT_, F_>, &raised, pl, st); }      \
+    if (pl.RT == 1 && pl.args.pair && pl.MT == MT_ && pl.occ2 && f16 == F_) {                               \
+        static PerDeviceLatch raised; e = launch_b16(&conv_b16_kernel_pair_occ2<MT_, F_>, &raised, pl, st); }
+#define UNETMI_B16_ALL(F_)                                                                                  \
+    UNETMI_B16(1, 1, false, F_) UNETMI_B16(1, 2, false, F_) UNETMI_B16(2, 1, false, F_) UNETMI_B16(2, 2, false, F_) \
+    UNETMI_B16(3, 1, false, F_) UNETMI_B16(3, 2, false, F_) UNETMI_B16(4, 1, false, F_)                     \
+    UNETMI_B16(1, 1, true, F_) UNETMI_B16(1, 2, true, F_)                                                   \
+    UNETMI_B16_OCC2(1, 1, F_) UNETMI_B16_OCC2(1, 2, F_) UNETMI_B16_OCC2(2, 1, F_) UNETMI_B16_OCC2(2, 2, F_) \
+    UNETMI_B16_OCC2(3, 1, F_) UNETMI_B16_OCC2(3, 2, F_) UNETMI_B16_OCC2(4, 1, F_)                           \
+    UNETMI_B16_PAIR(1, F_) UNETMI_B16_PAIR(2, F_) UNETMI_B16_PAIR(3, F_)                                    \
+    UNETMI_B16_RT2(1, F_) UNETMI_B16_RT2(2, F_) UNETMI_B16_RT2(3, F_)
+    UNETMI_B16_ALL(false)
+    UNETMI_B16_ALL(true)
+#undef UNETMI_B16_ALL
 #undef UNETMI_B16_RT2
 #undef UNETMI_B16_OCC2
 #undef UNETMI_B16_PAIR
@@ -1149,7 +1222,7 @@ int unetmi_conv2d_b16_nchw_fwd(const UnetmiConvDesc* d, const void* in0, const v
                                const float* gate, const float* residual, float* out, void* stream) {
     if (!d) return api_fail(UNETMI_E_BAD_ARG, "null descriptor");
     UnetmiConvDesc dd = *d;
-    dd.reserved[2] = 1;                         // fp32 NCHW output
+    dd.reserved[2] = (dd.reserved[2] & UNETMI_B16_IN_F16) | UNETMI_B16_OUT_NCHW_F32;
     return conv2d_b16_launch(&dd, in0, in1, wpacked, bias, scale, shift, act_param, gate, nullptr, nullptr, 0,
                              UNETMI_ACT_NONE, 0, out, stream, residual);
 }
@@ -1170,11 +1243,14 @@ int unetmi_conv2d_b16_head_fwd(const UnetmiConvDesc* d, const void* in0, const v
 }
 
 int unetmi_blocked_from_nchw(int N, int C, int HW, const void* src, int src_dtype, void* dst, void* stream) {
-    return unetmi_blocked_from_nchw_sum(N, C, HW, src, nullptr, src_dtype, dst, stream);
+    return unetmi_blocked_from_nchw_sum(N, C, HW, src, nullptr, src_dtype, dst, UNETMI_DTYPE_BF16, stream);
 }
 
 int unetmi_blocked_from_nchw_sum(int N, int C, int HW, const void* src, const void* src2, int src_dtype, void* dst,
-                                 void* stream) {
+                                 int dst_dtype, void* stream) {
+    if (dst_dtype != UNETMI_DTYPE_BF16 && dst_dtype != UNETMI_DTYPE_F16)
+        return api_fail(UNETMI_E_BAD_DESC, "blocked_from_nchw: the blocked tensor is bfloat16 or fp16");
+    const int dst_f16 = dst_dtype == UNETMI_DTYPE_F16;
     if (N < 0 || C < 1 || HW < 1) return api_fail(UNETMI_E_BAD_DESC, "blocked_from_nchw: bad sizes");
     if (N == 0) return UNETMI_OK;
     if (!src || !dst) return api_fail(UNETMI_E_BAD_ARG, "blocked_from_nchw: null pointer");
@@ -1182,14 +1258,17 @@ int unetmi_blocked_from_nchw_sum(int N, int C, int HW, const void* src, const vo
     if (N > 65535 || CB > 65535) return api_fail(UNETMI_E_UNSUPPORTED, "blocked_from_nchw: N or C too large");
     const dim3 grid((HW + 1023) / 1024, CB, N);              // four pixels per thread
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (src_dtype == UNETMI_DTYPE_BF16) hipLaunchKernelGGL((to_blocked_kernel<true>), grid, dim3(256), 0, st, src, src2, static_cast<char*>(dst), C, CB, HW);
-    else if (src_dtype == UNETMI_DTYPE_F32) hipLaunchKernelGGL((to_blocked_kernel<false>), grid, dim3(256), 0, st, src, src2, static_cast<char*>(dst), C, CB, HW);
+    if (src_dtype == UNETMI_DTYPE_BF16) hipLaunchKernelGGL((to_blocked_kernel<true>), grid, dim3(256), 0, st, src, src2, static_cast<char*>(dst), C, CB, HW, dst_f16);
+    else if (src_dtype == UNETMI_DTYPE_F32) hipLaunchKernelGGL((to_blocked_kernel<false>), grid, dim3(256), 0, st, src, src2, static_cast<char*>(dst), C, CB, HW, dst_f16);
     else return api_fail(UNETMI_E_BAD_DESC, "blocked_from_nchw: unknown dtype");
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("blocked_from_nchw launch: ") + hipGetErrorString(e));
 }
 
-int unetmi_nchw_from_blocked(int N, int C, int HW, const void* src, void* dst, int dst_dtype, void* stream) {
+int unetmi_nchw_from_blocked(int N, int C, int HW, const void* src, int src_dtype, void* dst, int dst_dtype, void* stream) {
+    if (src_dtype != UNETMI_DTYPE_BF16 && src_dtype != UNETMI_DTYPE_F16)
+        return api_fail(UNETMI_E_BAD_DESC, "nchw_from_blocked: the blocked tensor is bfloat16 or fp16");
+    const int src_f16 = src_dtype == UNETMI_DTYPE_F16;
     if (N < 0 || C < 1 || HW < 1) return api_fail(UNETMI_E_BAD_DESC, "nchw_from_blocked: bad sizes");
     if (N == 0) return UNETMI_OK;
     if (!src || !dst) return api_fail(UNETMI_E_BAD_ARG, "nchw_from_blocked: null pointer");
@@ -1197,8 +1276,8 @@ int unetmi_nchw_from_blocked(int N, int C, int HW, const void* src, void* dst, i
     if (N > 65535 || CB > 65535) return api_fail(UNETMI_E_UNSUPPORTED, "nchw_from_blocked: N or C too large");
     const dim3 grid((HW + 255) / 256, CB, N);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dst_dtype == UNETMI_DTYPE_BF16) hipLaunchKernelGGL((from_blocked_kernel<true>), grid, dim3(256), 0, st, static_cast<const char*>(src), dst, C, CB, HW);
-    else if (dst_dtype == UNETMI_DTYPE_F32) hipLaunchKernelGGL((from_blocked_kernel<false>), grid, dim3(256), 0, st, static_cast<const char*>(src), dst, C, CB, HW);
+    if (dst_dtype == UNETMI_DTYPE_BF16) hipLaunchKernelGGL((from_blocked_kernel<true>), grid, dim3(256), 0, st, static_cast<const char*>(src), dst, C, CB, HW, src_f16);
+    else if (dst_dtype == UNETMI_DTYPE_F32) hipLaunchKernelGGL((from_blocked_kernel<false>), grid, dim3(256), 0, st, static_cast<const char*>(src), dst, C, CB, HW, src_f16);
     else return api_fail(UNETMI_E_BAD_DESC, "nchw_from_blocked: unknown dtype");
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("nchw_from_blocked launch: ") + hipGetErrorString(e));

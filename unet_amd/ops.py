@@ -513,12 +513,13 @@ _LIBRARY.define("blocked_from_nchw(Tensor x) -> Tensor")
 _LIBRARY.define("nchw_from_blocked(Tensor data, int C, bool f32) -> Tensor")
 _LIBRARY.define("conv2d_b16_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
                 "Tensor shift, Tensor? act_param, Tensor? gate, int[] geom, int[] flags) -> Tensor")
-_LIBRARY.define("blocked_from_nchw_sum(Tensor x, Tensor? x2) -> Tensor")
+_LIBRARY.define("blocked_from_nchw_sum(Tensor x, Tensor? x2, bool f16=False) -> Tensor")
 _LIBRARY.define("conv2d_b16_nchw_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
                 "Tensor shift, Tensor? act_param, Tensor? gate, Tensor? residual, int[] geom, int[] flags) -> Tensor")
 _LIBRARY.define("conv2d_b16_head_fwd(Tensor x, int C0, Tensor? skip, int C1, Tensor wpacked, Tensor bias, Tensor scale, "
                 "Tensor shift, Tensor? act_param, Tensor? gate, Tensor head_w, Tensor? head_b, int[] geom, int[] flags) -> Tensor")
-# conv2d_wgrad flags = [transposed, in_mode]; conv2d_b16_fwd flags = [transposed, act, act_first, halves, nchw_out];
+# conv2d_wgrad flags = [transposed, in_mode]; conv2d_b16_fwd flags = [transposed, act, act_first, halves, nchw_out(, out_f16)]
+# (the operands' 16-bit format, bfloat16 or fp16, is the dtype of x; out_f16 asks for an fp16 blocked output);
 # conv2d_b16_head_fwd flags = [transposed, act, act_first, halves, head_act, interleaved];
 # conv2d_b16_nchw_fwd flags = [transposed, act, act_first, halves]
 
@@ -859,15 +860,16 @@ def blocks_for(C):
     return 2 * ((C + 15) // 16)
 
 
-def _blocked_from_nchw_sum_cuda(x, x2):
+def _blocked_from_nchw_sum_cuda(x, x2, f16=False):
     if not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
         raise ValueError("unetmi::blocked_from_nchw: contiguous 4-D device tensor expected")
     if x2 is not None and (x2.shape != x.shape or x2.dtype != x.dtype or x2.device != x.device or not x2.is_contiguous()):
         raise ValueError("unetmi::blocked_from_nchw_sum: x2 must match x in shape, dtype and device and be contiguous")
     N, C, H, W = x.shape
-    out = torch.empty((N, blocks_for(C), H, W, 8), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((N, blocks_for(C), H, W, 8), dtype=torch.float16 if f16 else torch.bfloat16, device=x.device)
     with torch.cuda.device(x.device):
-        check(_lib.lib.unetmi_blocked_from_nchw_sum(N, C, H * W, _ptr(x), _ptr(x2), dtype_code(x), _ptr(out), _stream(x)),
+        check(_lib.lib.unetmi_blocked_from_nchw_sum(N, C, H * W, _ptr(x), _ptr(x2), dtype_code(x), _ptr(out),
+                                                    _lib.DTYPE_F16 if f16 else _lib.DTYPE_BF16, _stream(x)),
               "unetmi_blocked_from_nchw_sum")
     return out
 
@@ -876,45 +878,58 @@ def _blocked_from_nchw_cuda(x):
     return _blocked_from_nchw_sum_cuda(x, None)
 
 
+def _blocked_dtype(t, name, op):
+    """A blocked 16-bit tensor: bfloat16 or fp16 (its dtype names the format); True for fp16."""
+    if t.dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError("unetmi::{}: {} must be a bfloat16 or float16 blocked tensor".format(op, name))
+    _dev(t, name, op, t.dtype)
+    return t.dtype == torch.float16
+
+
 def _nchw_from_blocked_cuda(data, C, f32):
-    _dev(data, "data", "nchw_from_blocked", torch.bfloat16)
+    src_f16 = _blocked_dtype(data, "data", "nchw_from_blocked")
     if data.dim() != 5 or data.shape[4] != 8 or data.shape[1] != blocks_for(C):
         raise ValueError("unetmi::nchw_from_blocked: data must be [N, 2*ceil(C/16), H, W, 8]")
     N, _, H, W, _ = data.shape
     out = torch.empty((N, C, H, W), dtype=torch.float32 if f32 else torch.bfloat16, device=data.device)
     with torch.cuda.device(data.device):
-        check(_lib.lib.unetmi_nchw_from_blocked(N, C, H * W, _ptr(data), _ptr(out),
+        check(_lib.lib.unetmi_nchw_from_blocked(N, C, H * W, _ptr(data), _lib.DTYPE_F16 if src_f16 else _lib.DTYPE_BF16, _ptr(out),
                                                 _lib.DTYPE_F32 if f32 else _lib.DTYPE_BF16, _stream(data)),
               "unetmi_nchw_from_blocked")
     return out
 
 
-def b16_desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, has_gate, halves, nchw_out):
+def b16_desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, has_gate, halves, nchw_out, in_f16=False,
+             out_f16=False):
+    """Descriptor of a 16-bit-operand layer; in_f16: inputs and weight image are fp16 (else bfloat16), out_f16: the
+    blocked output is stored as fp16."""
     d = make_desc(N, C0, C1, H, W, geom, [transposed, _lib.IN_CONCAT if C1 else _lib.IN_SINGLE, act, act_first],
                   act_pc, has_gate, 0, _lib.DTYPE_BF16)
     d.reserved[1] = halves
-    d.reserved[2] = int(nchw_out)
+    d.reserved[2] = ((_lib.B16_OUT_NCHW_F32 if nchw_out else 0) | (_lib.B16_IN_F16 if in_f16 else 0)
+                     | (_lib.B16_OUT_F16 if out_f16 else 0))
     return d
 
 
 def _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, transposed, act, act_first,
-                    halves, nchw_out, head, residual=None):
+                    halves, nchw_out, head, residual=None, out_f16=False):
     """Checks shared by the two bf16-operand entry points, then the launch.  head: None, or (head_w [P,K], head_b
     [P] | None, head_act, interleaved) for the decoder + 1x1 head launch."""
     what = "conv2d_b16_fwd" if head is None else "conv2d_b16_head_fwd"
-    _dev(x, "x", what, torch.bfloat16)
+    in_f16 = _blocked_dtype(x, "x", what)          # the operands' format: bfloat16 or fp16, both inputs alike
     if x.dim() != 5 or x.shape[4] != 8 or x.shape[1] != blocks_for(C0):
-        raise ValueError("unetmi::{}: x must be [N, 2*ceil(C0/16), H, W, 8] bfloat16".format(what))
+        raise ValueError("unetmi::{}: x must be [N, 2*ceil(C0/16), H, W, 8]".format(what))
     N, _, H, W, _ = x.shape
     if skip is not None:
-        _dev(skip, "skip", what, torch.bfloat16)
+        _dev(skip, "skip", what, x.dtype)
         if skip.dim() != 5 or skip.shape[0] != N or tuple(skip.shape[2:4]) != (H, W) or skip.shape[1] != blocks_for(C1):
             raise ValueError("unetmi::{}: skip {} does not match x {}".format(what, tuple(skip.shape), tuple(x.shape)))
     elif C1:
         raise ValueError("unetmi::{}: C1 without a skip tensor".format(what))
     K = geom[0]
     act_pc = 1 if (act_param is not None and act_param.numel() > 1) else 0
-    d = b16_desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, int(gate is not None), halves, nchw_out)
+    d = b16_desc(N, C0, C1, H, W, geom, transposed, act, act_first, act_pc, int(gate is not None), halves, nchw_out,
+                 in_f16, out_f16)
     expect = _lib.lib.unetmi_conv2d_b16_packed_weight_bytes(ctypes.byref(d))
     if expect == 0:
         raise _lib.UnetmiError("conv2d_b16: " + _lib.last_error(), _lib.E_BAD_DESC)
@@ -949,7 +964,8 @@ def _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gat
             if tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous():
                 raise ValueError("unetmi::{}: residual must be a contiguous fp32 [N,K,OH,OW] tensor".format(what))
     else:
-        out = torch.empty((N, blocks_for(K), d.OH, d.OW, 8), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((N, blocks_for(K), d.OH, d.OW, 8), dtype=torch.float16 if out_f16 else torch.bfloat16,
+                          device=x.device)
     with torch.cuda.device(x.device):
         obs = _launch_observer
         if obs is not None:
@@ -975,9 +991,10 @@ def _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gat
 
 
 def _conv2d_b16_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, flags):
-    transposed, act, act_first, halves, nchw_out = flags
+    transposed, act, act_first, halves, nchw_out = flags[:5]
+    out_f16 = bool(flags[5]) if len(flags) > 5 else False
     return _conv2d_b16_run(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, transposed, act, act_first,
-                           halves, nchw_out, None)
+                           halves, nchw_out, None, out_f16=out_f16 and not nchw_out)
 
 
 def _conv2d_b16_nchw_fwd_cuda(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, residual, geom, flags):
@@ -1105,13 +1122,13 @@ def _(x, C0, skip, C1, wpacked, bias, scale, shift, act_param, gate, geom, flags
     OH, OW = conv_out_size(H, kh, sh, ph, dh, oph, flags[0]), conv_out_size(W, kw, sw, pw, dw, opw, flags[0])
     if flags[4]:
         return x.new_empty((N, K, OH, OW), dtype=torch.float32)
-    return x.new_empty((N, blocks_for(K), OH, OW, 8))
+    return x.new_empty((N, blocks_for(K), OH, OW, 8), dtype=torch.float16 if len(flags) > 5 and flags[5] else torch.bfloat16)
 
 
 @torch.library.register_fake("unetmi::blocked_from_nchw_sum")
-def _(x, x2):
+def _(x, x2, f16=False):
     N, C, H, W = x.shape
-    return x.new_empty((N, blocks_for(C), H, W, 8), dtype=torch.bfloat16)
+    return x.new_empty((N, blocks_for(C), H, W, 8), dtype=torch.float16 if f16 else torch.bfloat16)
 
 
 @torch.library.register_fake("unetmi::conv2d_b16_nchw_fwd")
