@@ -368,7 +368,8 @@ int unetmi_glu_fwd(int N, int K, int HW, const void* z, const float* scale, cons
  *   reserved[2]  bits: UNETMI_B16_OUT_NCHW_F32 = write out as plain fp32 NCHW [N,K,OH,OW] instead of the blocked
  *                layout (heads); UNETMI_B16_IN_F16 = both inputs and the weight image hold fp16 instead of bfloat16
  *                (same layout, same matrix rate, three more mantissa bits; a layer's inputs share one format);
- *                UNETMI_B16_OUT_F16 = the blocked output is stored as fp16 (values beyond +-65504 saturate).
+ *                UNETMI_B16_OUT_F16 = the blocked output is stored as fp16 (a value beyond +-65504 becomes infinity and
+ *                shows as NaN downstream -- it is not clipped).
  *                fp16 suits tensors of known modest range -- activations behind a BatchNorm -- and cuts the
  *                rounding error of a chain of layers about eightfold; a network input of unknown scale stays
  *                bfloat16. */

@@ -577,7 +577,7 @@ def test_dsunet_bf16(device):
             assert got.dtype == torch.complex64
             what = "DSUNet bf16 " + ("operands, blocked layout" if matrix else "storage, NCHW")
             assert_bf16_close(got, want, what, max_tol=BF16_DEFAULT_PATH_TOL if matrix else None)
-    assert dev._blocked, "the blocked bf16 path was not taken"
+    assert dev._blocked and dev._blocked[1], "the blocked bf16 path was not taken"
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 9, 70), (1, 64, 257, 29), (3, 64, 3, 200), (8, 64, 6, 501), (8, 64, 13, 500)])
@@ -711,7 +711,7 @@ def test_dsunet_helper_wave_to_wave(device):
     dev.bf16_matrix = True
     with torch.no_grad():
         got16 = dev(wav.to(device), angle.to(device), mic.to(device))
-    assert got16.dtype == torch.float32 and dev.net._blocked, "the bfloat16-operand path was not taken"
+    assert got16.dtype == torch.float32 and dev.net._blocked and dev.net._blocked[1], "the bfloat16-operand path was not taken"
     assert_bf16_close(got16, want, "helper wave -> wave, bfloat16 operands")
 
 

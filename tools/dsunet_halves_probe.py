@@ -32,10 +32,23 @@ big = torch.randn(32, 8, 257, 512).to(torch.bfloat16).cuda()
 SVb, thb = torch.randn(32, 4, 514).cuda(), torch.randn(32, 2).cuda()
 with torch.no_grad():
     want = torch.view_as_real(ref(sf.float(), SV, theta))
+    for fmt_label, enc2 in (("fp16 behind enc0, enc0 one half", ()), ("fp16 behind enc0, enc0 two halves", (0,))):
+        dev.bf16_two_half_encoders, dev.operand_format = enc2, "fp16"
+        got = torch.view_as_real(dev(sf.cuda(), SV.cuda(), theta.cuda()).cpu())
+        l2, mx = ((got - want).norm() / want.norm()).item(), ((got - want).abs().max() / want.abs().max()).item()
+        for _ in range(3):
+            dev(big, SVb, thb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dev(big, SVb, thb)
+        torch.cuda.synchronize()
+        print("{:34s} L2 {:.2e} max-norm {:.2e}  {:.2f} ms / batch 32".format(fmt_label, l2, mx, (time.perf_counter() - t0) * 100))
     for label, enc2, dec2 in (("none", (), ()), ("enc0", (0,), ()), ("dec9", (), (9,)), ("enc0+dec9", (0,), (9,)),
                               ("enc0,1+dec9", (0, 1), (9,)), ("enc0+dec8,9", (0,), (8, 9)),
                               ("enc0,1+dec8,9", (0, 1), (8, 9)), ("all", tuple(range(10)), tuple(range(10)))):
         dev.bf16_two_half_encoders, dev.bf16_two_half_decoders = enc2, dec2
+        dev.operand_format = "bf16"
         object.__setattr__(dev, "_blocked", None)
         got = torch.view_as_real(dev(sf.cuda(), SV.cuda(), theta.cuda()).cpu())
         l2, mx = ((got - want).norm() / want.norm()).item(), ((got - want).abs().max() / want.abs().max()).item()

@@ -389,10 +389,22 @@ class DSUNet(nn.Module):
         self.bf16_matrix = True
         self.bf16_two_half_encoders = (0,)
         self.bf16_two_half_decoders = (L - 1,)
+        # 16-bit format of the operands INSIDE that chain: "fp16" (default) keeps the network input and the first
+        # encoder's operands bfloat16 (an STFT of unknown scale) and runs everything behind the first BatchNorm on fp16
+        # operands -- same kernels, same matrix rate, three more mantissa bits; an activation beyond +-65504 becomes
+        # infinity and shows as NaN in the mask (set "bf16" for such a model);
+        # "bf16" keeps bfloat16 throughout (then the last decoder takes two weight halves as well).
+        self.operand_format = "fp16"
 
     def _blocked_layers(self):
         """BlockedConv per encoder / decoder / head, or False when a layer is outside that kernel."""
-        if self._blocked is None:
+        fmt = self.operand_format
+        if fmt not in ("fp16", "bf16"):
+            raise ValueError("DSUNet.operand_format is 'fp16' or 'bf16'")
+        e2 = tuple(self.bf16_two_half_encoders)
+        d2 = tuple(self.bf16_two_half_decoders) if fmt == "bf16" else ()       # fp16 weights need no second half there
+        key = (fmt, e2, d2)
+        if self._blocked is None or self._blocked[0] != key:
             from .blocked import BlockedConv
             ok = isinstance(self.BTN, nn.Identity)
             for m in list(self.encoders) + list(self.decoders):
@@ -411,17 +423,17 @@ class DSUNet(nn.Module):
                 # mask without being averaged by later layers).  The head is not a layer of its own: the last decoder
                 # keeps its result in the fp32 accumulators and applies the 1x1 head and the squash there
                 # (BlockedConv.with_head), so neither that tensor nor the head's weights are ever rounded.
-                # Measured at T=512, batch 32 (tools/dsunet_halves_probe.py full; max-norm error / ms): no layer 1.18e-2 /
-                # 6.07, these two 7.8e-3 / 6.82, the first two encoders and last two decoders 7.0e-3 / 7.50,
-                # every layer 6.7e-3 / 10.2.
-                e2, d2 = self.bf16_two_half_encoders, self.bf16_two_half_decoders
-                built = dict(enc=[BlockedConv(m.conv, m.bn, m.relu, halves=2 if i in e2 else 1)
+                # Measured at T=512, batch 32 (tools/dsunet_halves_probe.py full; max-norm error / ms), all bfloat16: no
+                # layer 1.18e-2 / 6.07, these two 7.8e-3 / 6.82, the first two encoders and last two decoders
+                # 7.0e-3 / 7.50, every layer 6.7e-3 / 10.2.  With fp16 operands behind the first encoder (whose own
+                # weights keep their two bfloat16 halves: its input is bfloat16) no other layer needs a second half.
+                built = dict(enc=[BlockedConv(m.conv, m.bn, m.relu, halves=2 if i in e2 else 1, out_fmt=fmt)
                                   for i, m in enumerate(self.encoders)],
-                             dec=[BlockedConv(m.transconv, m.bn, m.relu, halves=2 if i in d2 else 1)
+                             dec=[BlockedConv(m.transconv, m.bn, m.relu, halves=2 if i in d2 else 1, out_fmt=fmt)
                                   for i, m in enumerate(self.decoders)],
                              head_act=squash[0])
-            object.__setattr__(self, "_blocked", built)
-        return self._blocked
+            object.__setattr__(self, "_blocked", (key, built))
+        return self._blocked[1]
 
     def _forward_blocked(self, layers, sf, attract):
         from .blocked import BlockedTensor

@@ -53,10 +53,11 @@ typedef _Float16 b16_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned b16_pack2(float lo, float hi) {        // v_cvt_pk_bf16_f32: nearest-even
     return __builtin_bit_cast(unsigned, __builtin_convertvector(b16_f32x2{lo, hi}, b16_bf16x2));
 }
-// two fp16 values, nearest-even, saturating at the largest finite value (a NaN stays a NaN)
-__device__ __forceinline__ float b16_sat_f16(float v) { return v != v ? v : fminf(fmaxf(v, -65504.f), 65504.f); }
+// two fp16 values, nearest-even.  A magnitude beyond the largest finite fp16 value (65504) becomes infinity, as the
+// format defines, and turns into NaN in the next layer's products: a tensor that does not fit the format shows in
+// the result instead of being clipped silently.
 __device__ __forceinline__ unsigned b16_pack2_f16(float lo, float hi) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(b16_f32x2{b16_sat_f16(lo), b16_sat_f16(hi)}, b16_f16x2));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(b16_f32x2{lo, hi}, b16_f16x2));
 }
 // the 16-bit storage format of a blocked tensor is a run-time property of the layer's OUTPUT
 __device__ __forceinline__ unsigned b16_pack2_as(float lo, float hi, int f16) {
@@ -833,7 +834,7 @@ static float host_bf16_to_f32(unsigned short b) {
     return v;
 }
 
-// fp32 -> fp16 bits, nearest-even, saturating at the largest finite value (what the device's conversion does)
+// fp32 -> fp16 bits for the weight image, nearest-even; a weight beyond the largest finite value saturates
 static unsigned short host_f16(float v) {
     unsigned u;
     std::memcpy(&u, &v, 4);
