@@ -135,8 +135,8 @@ def cpu_baseline(threads):
 def other_configs(dev, steps=5, warmup=2, batch=32):
     """The other benchmark workloads on this GPU, a few steps each with inputs resident (N=1, after the headline
     measurement; they do not enter value / config / roofline): UNet20 at T=509 + ratio-filter application,
-    ResUNet and DSUNet in fp32 and on bfloat16 inputs (batch 32 = one GPU's share) and the training step at
-    batch 8.  ``frac`` prices the whole step against the peak named by ``bound`` (tools/bench_configs.py)."""
+    ResUNet and DSUNet in fp32, the headline's UNet, UNet20, ResUNet and DSUNet on bfloat16 inputs (batch 32 = one
+    GPU's share) and the training step at batch 8.  ``frac`` prices the whole step against the peak named by ``bound`` (tools/bench_configs.py)."""
     spec = importlib.util.spec_from_file_location("unetmi_bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
     cfg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cfg)
@@ -153,7 +153,7 @@ def other_configs(dev, steps=5, warmup=2, batch=32):
         return (time.perf_counter() - t0) / steps
 
     with torch.no_grad():
-        for dtype, names in (("f32", ["unet20", "resunet", "dsunet"]), ("bf16", ["resunet", "dsunet"])):
+        for dtype, names in (("f32", ["unet20", "resunet", "dsunet"]), ("bf16", ["unet", "unet20", "resunet", "dsunet"])):
             g = torch.Generator().manual_seed(4321)
             for w in cfg.iter_workloads(names, batch, dev, dtype, g):
                 sec = timed(w["fn"])

@@ -209,6 +209,42 @@ def test_resunet_bf16_full_length(device):
         assert l2 <= BF16_TOL and mx <= 2e-2
 
 
+def test_unet_and_unet20_bf16_full_length(device):
+    """UNet (default config) and cRFUNet.UNet20 on a bfloat16 input at T=509: the default 16-bit-operand path (fp16
+    operands behind the first encoder, blocked layout; UNet.py:22-48, cRFUNet.py:279-324) against the fp32 oracle on the
+    same input -- relative L2 and max-norm within 1e-2."""
+    import oracle
+    import unet_amd
+    from unet_amd.seeding import normal, uniform
+    ref = oracle.UNet(*oracle.default_unet(c_in=2, c_last=1, f_dim=32)).eval()
+    unet_amd.seeded_fill_(ref, seed=5)
+    dev = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=32))
+    dev.load_state_dict(ref.state_dict(), strict=True)
+    dev.eval().to(device)
+    x = normal("unet_bf16_full/x", (2, 2, 257, 509), seed=6).to(torch.bfloat16)
+    with torch.no_grad():
+        want = ref(x.float())
+        got = dev(x.to(device))
+    assert got.dtype == torch.bfloat16 and dev._blocked[1], "the 16-bit-operand path was not taken"
+    l2, mx = bf16_figures(got, want)
+    print("UNet bf16 input T=509 (fp16 operands behind the first encoder): relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+    assert l2 <= BF16_TOL and mx <= BF16_TOL
+    ref20 = oracle.UNet20().eval()
+    unet_amd.seeded_fill_(ref20, seed=21)
+    dev20 = unet_amd.UNet20()
+    dev20.load_state_dict(ref20.state_dict(), strict=True)
+    ref20.T = dev20.T = 509
+    dev20.eval().to(device)
+    x20 = uniform("unet20_bf16_full/x", (1, 14, 257, 509), 0.0, 1.0, seed=22).to(torch.bfloat16)
+    with torch.no_grad():
+        want20 = ref20(x20.float())
+        got20 = dev20(x20.to(device))
+    assert got20.dtype == torch.complex64 and dev20._blocked[1]
+    l2, mx = bf16_figures(got20, want20)
+    print("UNet20 bf16 input T=509 (fp16 operands behind the first encoder): relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+    assert l2 <= 2e-3 and mx <= 2e-3
+
+
 def test_dsunet_bf16_full_length(device):
     """DSUNet on a bfloat16 input at T=512 (batch 2), 16-bit operands on the blocked layout (the default for a
     bfloat16 input), against the fp32 oracle (DSUNet.py:582-628): both figures within 1e-2 -- with fp16 operands

@@ -311,10 +311,11 @@ def test_udss_cmea_masks_and_application(device):
 
 
 def test_udss_bf16(device):
-    """UDSS on a bfloat16 input.  Default: widened to fp32, i.e. the fp32 bar.  Opt-in (``bf16_matrix``): bfloat16
-    operands on the blocked layout, the 256-real-channel bottleneck encoder split over two launches.  For that
-    path only the relative L2 error is held to 1e-2: bfloat16 activations through this network's 21 complex layers
-    leave single points up to 6e-2 of the output range off, with exact weights too (printed)."""
+    """UDSS on a bfloat16 input.  Default: widened to fp32, i.e. the fp32 bar.  Opt-in (``bf16_matrix``): 16-bit
+    operands on the blocked layout, the 256-real-channel bottleneck encoder split over two launches.  With fp16
+    operands behind the first encoder (``operand_format = "fp16"``, the default of that path) the relative L2 error
+    is held to 1e-2 and the max-norm error to 1.5e-2 (measured: 1.3e-3 and 9.4e-3); with bfloat16 operands throughout only the relative L2 error is: bfloat16 activations through this
+    network's 21 complex layers leave single points up to 6e-2 of the output range off, with exact weights too."""
     import numpy as np
     import oracle
     import unet_amd
@@ -335,6 +336,13 @@ def test_udss_bf16(device):
         assert got.dtype == torch.complex64
         assert_close(got, want, what="UDSS bf16 input widened to fp32")
         dev.bf16_matrix = True
+        assert dev.operand_format == "fp16"
+        got = dev(sf.to(device), SV.to(device), theta.to(device))
+        g, w = torch.view_as_real(got.cpu()), torch.view_as_real(want)
+        l2, mx = ((g - w).norm() / w.norm()).item(), ((g - w).abs().max() / w.abs().max()).item()
+        print("UDSS fp16 operands behind the first encoder: relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+        assert l2 <= 1e-2 and mx <= 1.5e-2          # measured 1.3e-3 / 9.4e-3
+        dev.operand_format = "bf16"
         for halves in (2, 1):
             dev.bf16_weight_halves = halves
             got = dev(sf.to(device), SV.to(device), theta.to(device))

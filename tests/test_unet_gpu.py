@@ -103,10 +103,10 @@ def _bf16_errors(got, want):
 
 
 def test_unet_and_unet20_bf16_operands(device):
-    """Opt-in (``bf16_matrix``): a bfloat16 input through the whole concat shell with bfloat16 operands (channel-blocked
-    layout, bf16 MFMA), against the fp32 oracle on the same (bf16-representable) input.  Held to relative L2 <= 1e-2;
-    the max-norm error is printed -- for this network it is 2e-2..4e-2 with bfloat16 activations whether the products
-    are bf16 or fp32, which is why the path is not the default."""
+    """A bfloat16 input through the whole concat shell with 16-bit operands (channel-blocked layout, the default for
+    a bfloat16 input), against the fp32 oracle on the same (bf16-representable) input.  With fp16 operands behind the
+    first encoder (the default) both error figures are held to the bfloat16 bar of 1e-2; with bfloat16 operands
+    throughout, or bfloat16 storage on the NCHW kernels, only relative L2 is (their max-norm is 2e-2..4e-2 on UNet)."""
     import oracle
     import unet_amd
     from unet_amd.seeding import normal, uniform
@@ -115,16 +115,21 @@ def test_unet_and_unet20_bf16_operands(device):
     x = normal("unet_bf16/x", (2, 2, 257, 45), seed=6).to(torch.bfloat16)
     with torch.no_grad():
         want = ref(x.float())
-        assert dev.bf16_matrix is False
+        assert dev.bf16_matrix is True and dev.operand_format == "fp16"
+        dev.bf16_matrix = False
         stor = dev(x.to(device))
         dev.bf16_matrix = True
         got = dev(x.to(device))
-    assert got.dtype == torch.bfloat16 and dev._blocked, "the bfloat16-operand path was not taken"
+        dev.operand_format = "bf16"
+        got_b = dev(x.to(device))
+    assert got.dtype == torch.bfloat16 and dev._blocked[1], "the 16-bit-operand path was not taken"
     l2, mx = _bf16_errors(got, want)
+    l2b, mxb = _bf16_errors(got_b, want)
     l2s, mxs = _bf16_errors(stor, want)
-    print("UNet bf16 operands: relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+    print("UNet fp16 operands behind enc0: relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+    print("UNet bf16 operands: relative L2 {:.3e}, max-norm {:.3e}".format(l2b, mxb))
     print("UNet bf16 storage : relative L2 {:.3e}, max-norm {:.3e}".format(l2s, mxs))
-    assert l2 <= 1e-2 and l2s <= 1e-2
+    assert l2 <= 1e-2 and mx <= 1e-2 and l2b <= 1e-2 and l2s <= 1e-2
 
     ref20 = oracle.UNet20().eval()
     unet_amd.seeded_fill_(ref20, seed=21)
@@ -135,12 +140,17 @@ def test_unet_and_unet20_bf16_operands(device):
     x20 = uniform("unet20_bf16/x", (2, 14, 257, 29), 0.0, 1.0, seed=22).to(torch.bfloat16)
     with torch.no_grad():
         want20 = ref20(x20.float())
+        dev20.bf16_matrix = False
         stor20 = dev20(x20.to(device))
         dev20.bf16_matrix = True
         got20 = dev20(x20.to(device))
-    assert got20.dtype == torch.complex64 and tuple(got20.shape) == tuple(want20.shape) and dev20._blocked
+        dev20.operand_format = "bf16"
+        got20_b = dev20(x20.to(device))
+    assert got20.dtype == torch.complex64 and tuple(got20.shape) == tuple(want20.shape) and dev20._blocked[1]
     l2, mx = _bf16_errors(got20, want20)
+    l2b, mxb = _bf16_errors(got20_b, want20)
     l2s, mxs = _bf16_errors(stor20, want20)
-    print("UNet20 bf16 operands: relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+    print("UNet20 fp16 operands behind enc0: relative L2 {:.3e}, max-norm {:.3e}".format(l2, mx))
+    print("UNet20 bf16 operands: relative L2 {:.3e}, max-norm {:.3e}".format(l2b, mxb))
     print("UNet20 bf16 storage : relative L2 {:.3e}, max-norm {:.3e}".format(l2s, mxs))
-    assert l2 <= 1e-2 and l2s <= 1e-2
+    assert l2 <= 2e-3 and mx <= 2e-3 and l2b <= 1e-2 and l2s <= 1e-2

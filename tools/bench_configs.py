@@ -77,9 +77,17 @@ def iter_workloads(names, B, dev, dtype, g):
     from unet_amd.ops import crf_apply
     act = torch.bfloat16 if dtype == "bf16" else torch.float32
     want = lambda n: names is None or n in names  # noqa: E731
+    if want("unet"):
+        net = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=32))
+        unet_amd.seeded_fill_(net, seed=0)
+        net.eval().to(dev)
+        x = torch.randn((B, 2, 257, 509), generator=g).to(dev).to(act)
+        yield dict(name="unet", fn=lambda: net(x), gflop=64.34, dtype=dtype, bf16_operands=dtype == "bf16", hbm_gb=None,
+                   workload="UNet default config forward, [B,2,257,509]" +
+                            (" bfloat16 input: 16-bit operands (fp16 behind the first encoder)" if dtype == "bf16" else ""))
+        del net, x
     if want("unet20"):
         net = unet_amd.UNet20()
-        net.bf16_matrix = True                       # with bf16: bfloat16 operands (opt-in for this network)
         unet_amd.seeded_fill_(net, seed=21)
         net.T = 509
         net.eval().to(dev)

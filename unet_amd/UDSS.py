@@ -171,8 +171,9 @@ class _ComplexLayer:
         self._twins[(C0, C1)] = fused
         return fused
 
-    def blocked(self, x, skip=None, gate=None, nchw_out=False, halves=1):
-        """The same layer on channel-blocked bfloat16 tensors (unet_amd/blocked.py).  The bf16 kernel takes at
+    def blocked(self, x, skip=None, gate=None, nchw_out=False, halves=1, out_fmt="bf16"):
+        """The same layer on channel-blocked 16-bit tensors (unet_amd/blocked.py; operands in the input's format,
+        output stored as ``out_fmt``).  The 16-bit kernel takes at
         most 128 output channels per launch; a wider layer (the 128-complex-channel bottleneck encoder) runs as
         two launches, real outputs and imaginary outputs, whose blocks are then joined."""
         from .blocked import BlockedConv, BlockedTensor
@@ -180,11 +181,11 @@ class _ComplexLayer:
         C1 = 0 if skip is None else skip.C // 2
         fused = self._twin(C0, C1)
         layers = getattr(fused, "blocked_layers", None)
-        if layers is None or fused.blocked_halves != halves:
+        if layers is None or fused.blocked_halves != (halves, out_fmt):
             twin, norm = fused.twin_modules
             K2 = twin.out_channels
             if K2 <= 128:
-                layers = [BlockedConv(twin, norm, self.act, halves=halves, nchw_out=nchw_out)]
+                layers = [BlockedConv(twin, norm, self.act, halves=halves, nchw_out=nchw_out, out_fmt=out_fmt)]
             else:
                 transposed = isinstance(twin, nn.ConvTranspose2d)
                 K = K2 // 2
@@ -203,9 +204,9 @@ class _ComplexLayer:
                             pn = nn.BatchNorm2d(K, eps=norm.eps).to(twin.weight.device).eval()
                             for name in ("weight", "bias", "running_mean", "running_var"):
                                 getattr(pn, name).copy_(getattr(norm, name)[h * K:(h + 1) * K])
-                    layers.append(BlockedConv(part, pn, self.act, halves=halves, nchw_out=nchw_out))
+                    layers.append(BlockedConv(part, pn, self.act, halves=halves, nchw_out=nchw_out, out_fmt=out_fmt))
             fused.blocked_layers = layers
-            fused.blocked_halves = halves
+            fused.blocked_halves = (halves, out_fmt)
         if len(layers) == 1:
             g = None if gate is None else torch.cat([gate, gate], dim=1).contiguous()
             return layers[0](x, skip, g)
@@ -630,12 +631,16 @@ class UDSS(nn.Module):
         self.encoders = nn.ModuleList(encs)
         self.attractors = nn.ModuleList(self.attractEncoders)
         self._head = None
-        # A bfloat16 input is widened to fp32 by default.  True: bfloat16 operands on the matrix cores over the
-        # channel-blocked layout (unet_amd/blocked.py), 4-6x faster -- opt-in, because bfloat16 activations between
-        # the 21 complex layers of this network cost 7e-3 relative L2 error and up to 6e-2 of the output range at
-        # single points, whatever the weights' precision (measured against the fp32 CPU forward).
+        # A bfloat16 input is widened to fp32 by default.  True: 16-bit operands on the matrix cores over the
+        # channel-blocked layout (unet_amd/blocked.py), 4-6x faster.  operand_format "fp16" (default): the input and
+        # the first encoder's operands stay bfloat16 (that layer takes two weight halves), everything behind its
+        # BatchNorm is fp16.  With "bf16" throughout, bfloat16 activations between the 21 complex layers of this
+        # network cost 7e-3 relative L2 error and up to 6e-2 of the output range at single points, whatever the
+        # weights' precision (measured against the fp32 CPU forward).
         self.bf16_matrix = False
-        # 2: each weight goes in as bfloat16 + its rounding remainder (two MFMAs); with 1 the L2 error is 1.04e-2
+        self.operand_format = "fp16"
+        # "bf16" format only: 2 = each weight goes in as bfloat16 + its rounding remainder (two MFMAs); with 1 the
+        # L2 error is 1.04e-2
         self.bf16_weight_halves = 2
 
     def set_size(self, model_complexity, model_depth=20, input_channels=1):
@@ -695,24 +700,29 @@ class UDSS(nn.Module):
     def _forward_blocked(self, sf, attract):
         from .blocked import BlockedTensor
         L = self.model_length
+        fmt = self.operand_format
+        if fmt not in ("fp16", "bf16"):
+            raise ValueError("UDSS.operand_format is 'fp16' or 'bf16'")
+        halves = self.bf16_weight_halves if fmt == "bf16" else 1           # fp16 weights need no second half
         x = BlockedTensor.from_nchw(stack_complex(sf))
         skips = []
         for i, enc in enumerate(self.encoders):
             skips.append(x)
             if enc._layer is None:
                 object.__setattr__(enc, "_layer", _ComplexLayer(enc.conv, enc.bn, enc.relu))
-            x = enc._layer.blocked(x, None, self.attractEncoders[i](attract).float(), halves=self.bf16_weight_halves)
+            x = enc._layer.blocked(x, None, self.attractEncoders[i](attract).float(),
+                                   halves=2 if (i == 0 and fmt == "fp16") else halves, out_fmt=fmt)
         for i, dec in enumerate(self.decoders):
             if dec._layer is None:
                 object.__setattr__(dec, "_layer", _ComplexLayer(dec.transconv, dec.bn, dec.relu))
-            x = dec._layer.blocked(x, None if i == 0 else skips[L - i], halves=self.bf16_weight_halves)
+            x = dec._layer.blocked(x, None if i == 0 else skips[L - i], halves=halves, out_fmt=fmt)
         if self._head is None:
             act = nn.Tanh() if isinstance(self.mask, CRM) else None
             object.__setattr__(self, "_head", _ComplexLayer(self.linear, None, act))
         head = self._head
         if getattr(head, "_plain", None) is None:
             head._plain = _ComplexLayer(self.linear, None, None)
-        m = head._plain.blocked(x, nchw_out=True, halves=self.bf16_weight_halves)     # fp32 [B, 2, F, T]
+        m = head._plain.blocked(x, nchw_out=True, halves=halves)     # fp32 [B, 2, F, T]
         if isinstance(self.mask, CRM):
             m = torch.tanh(m)
         if isinstance(self.mask, CMEA):

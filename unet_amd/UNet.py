@@ -75,9 +75,12 @@ def blocked_shell_layers(net):
     """BlockedConv per encoder / decoder / head for the bfloat16-operand path (unet_amd/blocked.py), or False when a
     layer is outside what that kernel serves: Encoder / Decoder blocks with eval BatchNorm2d and LeakyReLU / PReLU /
     ReLU, at most 128 output channels, identity res-paths and bottlenecks."""
+    fmt = getattr(net, "operand_format", "fp16")
+    if fmt not in ("fp16", "bf16"):
+        raise ValueError("operand_format is 'fp16' or 'bf16'")
     cached = getattr(net, "_blocked", None)
-    if cached is not None:
-        return cached
+    if cached is not None and cached[0] == fmt:
+        return cached[1]
     from . import _lib
     from .blocked import BlockedConv
     from .fused import activation_code
@@ -93,16 +96,21 @@ def blocked_shell_layers(net):
             conv.groups == 1 and getattr(conv, "padding_mode", "zeros") == "zeros"
     built = False
     if ok and net.linear.out_channels <= 128:
-        built = dict(enc=[BlockedConv(m.conv, m.bn, m.acti) for m in net.encoders],
-                     dec=[BlockedConv(m.transconv, m.bn, m.acti) for m in net.decoders],
+        # The network input (an STFT of unknown scale) and the first encoder's operands stay bfloat16 -- that layer
+        # takes its weights as two bfloat16 halves, it is bound by its activation traffic anyway -- and with
+        # operand_format "fp16" (default) every tensor behind its BatchNorm is stored, and multiplied, as fp16.
+        built = dict(enc=[BlockedConv(m.conv, m.bn, m.acti, halves=2 if i == 0 else 1, out_fmt=fmt)
+                          for i, m in enumerate(net.encoders)],
+                     dec=[BlockedConv(m.transconv, m.bn, m.acti, out_fmt=fmt) for m in net.decoders],
                      head=BlockedConv(net.linear, None, None, nchw_out=True))
-    object.__setattr__(net, "_blocked", built)
+    object.__setattr__(net, "_blocked", (fmt, built))
     return built
 
 
 def blocked_shell_forward(net, layers, x):
-    """The concat shell on channel-blocked bfloat16 tensors; returns the head's fp32 [B, K, F, T] output
-    before the mask activation."""
+    """The concat shell on channel-blocked 16-bit tensors; returns the head's fp32 [B, K, F, T] output before the mask
+    activation.  (Fusing UNet's 1x1 head into the last decoder, as DSUNet does, was measured: the one-column-tile
+    kernel a fused head needs makes the batch-64 forward 7.5 ms instead of 7.3, at the same error.)"""
     from .blocked import BlockedTensor
     t = BlockedTensor.from_nchw(x.contiguous())
     skips = []
@@ -136,11 +144,14 @@ class UNet(nn.Module):
         self.activation_mask = nn.Sigmoid()
         self._head = None
 
-    # Opt-in for bfloat16 inputs: bfloat16 operands on the matrix cores over the channel-blocked layout when every
-    # layer is one that kernel serves (False: the NCHW bfloat16-storage kernels with fp32 products).  Not the default:
-    # against the fp32 CPU forward it measures 7e-3 relative L2 error but up to 4e-2 of the mask range at single
-    # points (the storage-only path: 5e-3 and 2.3e-2), outside the 2e-2 max-norm bar of the bfloat16 configurations.
-    bf16_matrix = False
+    # bfloat16 inputs: 16-bit operands on the matrix cores over the channel-blocked layout when every layer is one that
+    # kernel serves (False: the NCHW bfloat16-storage kernels with fp32 products).  operand_format "fp16" (default):
+    # the input and the first encoder's operands stay bfloat16, every tensor behind its BatchNorm is fp16.  At the
+    # benchmark's size (batch 64, T=509) against the fp32 CPU forward: 7.3 ms, relative L2 2.3e-3, max-norm 7.8e-3;
+    # with "bf16" operands throughout 7.0 ms, 7.2e-3 / 4.2e-2; the storage-only path 46 ms, 5.4e-3 / 3.1e-2; the
+    # fp32 forward 35.2 ms.
+    bf16_matrix = True
+    operand_format = "fp16"
 
     def forward(self, x):
         require_device_tensor(x, "UNet")

@@ -55,6 +55,7 @@ class _FusedBlock(nn.Module):
     # (16x the fp32 rate) with fp32 accumulation and writes fp32 NCHW, an added tensor included; 2 = weights as
     # bfloat16 plus their rounding remainder.  Blocks the bf16 kernel does not serve keep the fp32 path.
     bf16_operands = 0
+    bf16_operand_format = "fp16"      # 16-bit format of those operands: "fp16" or "bf16"
 
     def _setup(self, conv_attr):
         self._conv_attr = conv_attr
@@ -125,11 +126,12 @@ class _FusedBlock(nn.Module):
         if parts is False:
             return None
         try:
+            # fp16 operands: these layers sit behind BatchNorms (modest range), and fp16 keeps three more bits
             if skip is not None and in_mode == _lib.IN_ADD:
-                xb, sb = BlockedTensor.from_nchw(x.contiguous(), addend=skip.contiguous()), None
+                xb, sb = BlockedTensor.from_nchw(x.contiguous(), addend=skip.contiguous(), fmt=self.bf16_operand_format), None
             else:
-                xb = BlockedTensor.from_nchw(x.contiguous())
-                sb = None if skip is None else BlockedTensor.from_nchw(skip.contiguous())
+                xb = BlockedTensor.from_nchw(x.contiguous(), fmt=self.bf16_operand_format)
+                sb = None if skip is None else BlockedTensor.from_nchw(skip.contiguous(), fmt=self.bf16_operand_format)
             outs = [layer(xb, sb, None, residual=None if residual is None else residual[:, lo:hi].contiguous())
                     for lo, hi, layer in parts]
             return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
