@@ -362,7 +362,8 @@ int unetmi_glu_fwd(int N, int K, int HW, const void* z, const float* scale, cons
  * consecutive channels of a pixel form one 16-byte record; channels padded with zeros to a multiple of 16).
  * Products run on the bf16 matrix instruction with fp32 accumulation; bias / BatchNorm / activation /
  * gate are applied to the fp32 accumulator.  Descriptor as for unetmi_conv2d_fwd, with
- *   in_mode      UNETMI_IN_SINGLE or UNETMI_IN_CONCAT (no add, no residual), K <= 128,
+ *   in_mode      UNETMI_IN_SINGLE or UNETMI_IN_CONCAT (no add, no residual); K <= 128, or a multiple of 128 (the
+ *                launch then has one grid column per 128-channel chunk and the weight image one image per chunk),
  *   reserved[1]  weight halves: 0/1 = weights rounded to bfloat16; 2 = a second image holds the rounding
  *                remainder and a second MFMA adds it (fp32-weight accuracy at twice the matrix work),
  *   reserved[2]  bits: UNETMI_B16_OUT_NCHW_F32 = write out as plain fp32 NCHW [N,K,OH,OW] instead of the blocked

@@ -72,6 +72,10 @@ CASES = [
     (90, 8, 90, (7, 1), (1, 1), (3, 0), (0, 0), True, 21, 33),
     (16, 0, 32, (3, 3), (1, 1), (1, 2), (0, 0), False, 9, 40),
     (20, 12, 64, (3, 3), (1, 1), (1, 1), (0, 0), False, 12, 65),
+    # more than 128 outputs: 128-channel chunks as a grid dimension (ResUNet's 384-channel layers, the LSTM's products)
+    (128, 0, 384, (3, 1), (1, 1), (0, 0), (0, 0), False, 5, 70),
+    (384, 0, 128, (3, 1), (1, 1), (0, 0), (0, 0), True, 3, 40),
+    (48, 0, 256, (1, 1), (1, 1), (0, 0), (0, 0), False, 9, 33),
     # edges: one pixel, one channel, tiles hanging over every border, time-only stride, dilation via a wide pad
     (1, 0, 1, (1, 1), (1, 1), (0, 0), (0, 0), False, 1, 1),
     (3, 0, 2, (3, 3), (1, 1), (1, 1), (0, 0), False, 2, 3),
@@ -183,6 +187,11 @@ def run_case(device, case, halves, N, with_head=True, fmt="bf16"):
         assert raw[:, K:].float().abs().max().item() == 0.0
     if not with_head:
         return
+    if K > 128:                                       # a layer of several 128-channel chunks takes no fused head
+        from unet_amd import _lib
+        with pytest.raises(UnetmiError, match="multiples of 128"):
+            layer.with_head(b0, b1, nn.Conv2d(K, 2, 1).to(device), _lib.ACT_TANH, gate=gate.to(device))
+        return
     # the layer + a 1x1 head + squash as one launch (the layer's result never leaves the fp32 accumulators):
     # planar and pixel-interleaved output, 1..4 head channels
     from unet_amd import _lib
@@ -221,4 +230,4 @@ def test_conv_b16_rejects(device):
     from unet_amd.blocked import _desc
     d = _desc(1, 16, 0, 8, 8, [200, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0], 0, 0, 0, 0, 0, 1, False)
     assert _lib.lib.unetmi_conv2d_b16_packed_weight_bytes(ctypes.byref(d)) == 0
-    assert "128 output channels" in _lib.last_error()
+    assert "multiples of 128" in _lib.last_error()

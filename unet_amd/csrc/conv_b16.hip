@@ -97,7 +97,9 @@ struct B16Args {
     const char* in0; const char* in1; const char* w;
     const float* bias; const float* scale; const float* shift; const float* act_param; const float* gate;
     void* out;
-    int N, H, W, OH, OW, K;
+    int N, H, W, OH, OW, K;  // K: output channels of ONE workgroup column (<= 128)
+    int Kfull;               // output channels of the layer: gridDim.y chunks of 128 when it has more than 128
+    unsigned w_chunk_bytes;  // size of one chunk's weight image
     int G0, G1;              // 16-channel groups of the two sources
     int sih, siw, tdh, tdw, soh, sow;
     int nphase, hl, din;     // weight halves (1 | 2); input prefetch distance in groups (1 | 2)
@@ -208,9 +210,11 @@ __device__ __forceinline__ void b16_wait_vm(int n) {
 // step's operands.  s_par rows then are A, B, -, slope, -.
 template <int MT, int NT, bool GEN, bool PAIR, bool FOLD>
 __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], const B16Args& p, const B16Phase& ph,
-                                             const float* s_par, int n, int oh, int j0, int half, int j) {
+                                             const float* s_par, int n, int oh, int j0, int half, int j, int kb) {
     static_assert(!(GEN && FOLD), "the folded form has leaky / ReLU / identity activations only");
-    const int CBo = 2 * ((p.K + 15) >> 4);
+    // kb: first output channel of this workgroup's chunk (0 unless the layer has more than 128 outputs)
+    const int CBo = 2 * ((p.Kfull + 15) >> 4);
+    const int kblk = kb >> 3;
     const size_t OHW = (size_t)p.OH * p.OW;
     size_t pix[NT];
     bool ok[NT];
@@ -271,17 +275,17 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
                 float add[2][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    add[0][r] = (p.residual && okc && c0 + r < p.K) ? p.residual[((size_t)n * p.K + c0 + r) * OHW + pixc] : 0.f;
-                    add[1][r] = (p.residual && okc && c0 + 4 + r < p.K) ? p.residual[((size_t)n * p.K + c0 + 4 + r) * OHW + pixc] : 0.f;
+                    add[0][r] = (p.residual && okc && c0 + r < p.K) ? p.residual[((size_t)n * p.Kfull + kb + c0 + r) * OHW + pixc] : 0.f;
+                    add[1][r] = (p.residual && okc && c0 + 4 + r < p.K) ? p.residual[((size_t)n * p.Kfull + kb + c0 + 4 + r) * OHW + pixc] : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     unsigned s0 = __builtin_bit_cast(unsigned, v[0][r]), s1 = __builtin_bit_cast(unsigned, v[1][r]);
                     swap_lane_halves(s0, s1);
                     if (okc && c0 + r < p.K)
-                        out[((size_t)n * p.K + c0 + r) * OHW + pixc] = __builtin_bit_cast(float, s0) + add[0][r];
+                        out[((size_t)n * p.Kfull + kb + c0 + r) * OHW + pixc] = __builtin_bit_cast(float, s0) + add[0][r];
                     if (okc && c0 + 4 + r < p.K)
-                        out[((size_t)n * p.K + c0 + 4 + r) * OHW + pixc] = __builtin_bit_cast(float, s1) + add[1][r];
+                        out[((size_t)n * p.Kfull + kb + c0 + 4 + r) * OHW + pixc] = __builtin_bit_cast(float, s1) + add[1][r];
                 }
             } else if (p.out_nchw_f32) {
 #pragma unroll
@@ -289,7 +293,7 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (ok[nt] && m0 + r < p.K) {
-                            const size_t o = ((size_t)n * p.K + m0 + r) * OHW + pix[nt];
+                            const size_t o = ((size_t)n * p.Kfull + kb + m0 + r) * OHW + pix[nt];
                             static_cast<float*>(p.out)[o] = p.residual ? v[nt][r] + p.residual[o] : v[nt][r];
                         }
             } else if constexpr (NT == 2) {
@@ -300,15 +304,15 @@ __device__ __forceinline__ void b16_epilogue(const b16_f32x16 (&acc)[MT][NT], co
                 unsigned hi0 = b16_pack2_as(v[0][2], v[0][3], p.out_f16), hi1 = b16_pack2_as(v[1][2], v[1][3], p.out_f16);
                 swap_lane_halves(lo0, lo1);
                 swap_lane_halves(hi0, hi1);
-                if ((half ? ok[1] : ok[0]) && blk < CBo) {
-                    char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + (half ? pix[1] : pix[0])) * 16;
+                if ((half ? ok[1] : ok[0]) && kblk + blk < CBo) {
+                    char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + kblk + blk) * OHW + (half ? pix[1] : pix[0])) * 16;
                     *reinterpret_cast<uint4*>(o) = uint4{lo0, hi0, lo1, hi1};
                 }
-            } else if (ok[0] && blk < CBo) {
+            } else if (ok[0] && kblk + blk < CBo) {
                 uint2 w2;
                 w2.x = b16_pack2_as(v[0][0], v[0][1], p.out_f16);
                 w2.y = b16_pack2_as(v[0][2], v[0][3], p.out_f16);
-                char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + blk) * OHW + pix[0]) * 16 + half * 8;
+                char* o = static_cast<char*>(p.out) + (((size_t)n * CBo + kblk + blk) * OHW + pix[0]) * 16 + half * 8;
                 *reinterpret_cast<uint2*>(o) = w2;
             }
         }
@@ -476,7 +480,9 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     const int n_w_instr = R * ntws * MT;
     const int nsub = p.hl * nchunk;                  // steps per channel group: weight half (outer) x tap-row chunk
     const int S = G * nsub;
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + p.ph[a].w_off), 0, (int)p.ph[a].w_bytes, 0x00020000);
+    const int kb = (int)blockIdx.y * 128;            // this workgroup's chunk of a layer with more than 128 outputs
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.w + (size_t)blockIdx.y * p.w_chunk_bytes + p.ph[a].w_off), 0, (int)p.ph[a].w_bytes, 0x00020000);
 
     auto issue_input = [&](int g) -> int {            // group g -> its ring slot; returns instructions issued
         if (g >= G) return 0;
@@ -514,7 +520,7 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
     // Can this workgroup's epilogue take the folded form (see b16_epilogue)?  One slope for all channels, affine
     // before the activation, and no negative gate value for this sample.
     float gv = 1.f;
-    if (tid < p.K && p.gate) gv = p.gate[(size_t)n * p.K + tid];
+    if (tid < p.K && p.gate) gv = p.gate[(size_t)n * p.Kfull + kb + tid];
     int* const s_flag = reinterpret_cast<int*>(s_par + (5 + (p.head_P ? kB16MaxHead : 0)) * MT * 32);
     if (tid == 0) *s_flag = 0;
     __syncthreads();
@@ -526,13 +532,13 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
         float par[5] = {0.f, 0.f, 0.f, 0.f, 0.f};       // channels past K produce exact zeros
         if (tid < p.K) {
             float slope = p.act == UNETMI_ACT_NONE ? 1.f : 0.f;                  // slope of the select: none = 1, ReLU = 0
-            if (p.act == UNETMI_ACT_LEAKY) slope = p.act_param[p.act_pc ? tid : 0];
+            if (p.act == UNETMI_ACT_LEAKY) slope = p.act_param[p.act_pc ? kb + tid : 0];
             par[3] = slope;
             if (fold) {
-                par[0] = p.scale[tid] * gv;
-                par[1] = (p.bias[tid] * p.scale[tid] + p.shift[tid]) * gv;
+                par[0] = p.scale[kb + tid] * gv;
+                par[1] = (p.bias[kb + tid] * p.scale[kb + tid] + p.shift[kb + tid]) * gv;
             } else {
-                par[0] = p.bias[tid]; par[1] = p.scale[tid]; par[2] = p.shift[tid]; par[4] = gv;
+                par[0] = p.bias[kb + tid]; par[1] = p.scale[kb + tid]; par[2] = p.shift[kb + tid]; par[4] = gv;
             }
         }
 #pragma unroll
@@ -707,11 +713,11 @@ __device__ __forceinline__ void conv_b16_body(const B16Args& p) {
         }
         if constexpr (!GEN) {
             if (fold) {
-                b16_epilogue<MT, NT, false, PAIR, true>(acc[rt], p, p.ph[a], s_par, n, oh, j0, half, j);
+                b16_epilogue<MT, NT, false, PAIR, true>(acc[rt], p, p.ph[a], s_par, n, oh, j0, half, j, kb);
                 return;
             }
         }
-        b16_epilogue<MT, NT, GEN, PAIR, false>(acc[rt], p, p.ph[a], s_par, n, oh, j0, half, j);
+        b16_epilogue<MT, NT, GEN, PAIR, false>(acc[rt], p, p.ph[a], s_par, n, oh, j0, half, j, kb);
     });
 }
 
@@ -813,6 +819,7 @@ __global__ __launch_bounds__(256) void from_blocked_kernel(const char* src, void
 struct B16Plan {
     B16Args args;
     int MT, NT, RT;
+    int kchunks;             // 128-channel output chunks (grid dimension y)
     bool occ2;
     unsigned grid;
     int kw0[kB16MaxPhase][2];
@@ -890,15 +897,20 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     if (OH != d.OH || OW != d.OW || OH < 1 || OW < 1) return bad("conv2d_b16: OH/OW do not match the geometry");
     B16Args& a = pl->args;
     std::memset(&a, 0, sizeof(a));
-    a.N = d.N; a.H = d.H; a.W = d.W; a.OH = OH; a.OW = OW; a.K = d.K;
+    // more than 128 output channels: chunks of 128 as a second grid dimension (every chunk the same kernel and
+    // weight-image shape, hence whole multiples only); no fused head there
+    if (d.K > 128 && (d.K % 128 != 0 || head_P)) return bad("conv2d_b16: more than 128 output channels come in multiples of 128 (and without a fused head)");
+    pl->kchunks = d.K > 128 ? d.K / 128 : 1;
+    if (pl->kchunks > 65535) return bad("conv2d_b16: too many output channels");
+    const int Kc = d.K > 128 ? 128 : d.K;
+    a.N = d.N; a.H = d.H; a.W = d.W; a.OH = OH; a.OW = OW; a.K = Kc; a.Kfull = d.K;
     a.G0 = (d.C0 + 15) / 16; a.G1 = (d.C1 + 15) / 16;
     a.hl = hl;
     a.act = d.act; a.act_first = d.act_first; a.act_pc = d.act_param_per_channel; a.out_nchw_f32 = (d.reserved[2] & UNETMI_B16_OUT_NCHW_F32) != 0;
     a.out_f16 = (d.reserved[2] & UNETMI_B16_OUT_F16) != 0;
     if (d.reserved[2] & ~(UNETMI_B16_OUT_NCHW_F32 | UNETMI_B16_IN_F16 | UNETMI_B16_OUT_F16))
         return bad("conv2d_b16: unknown bits in reserved[2]");
-    pl->MT = (d.K + 31) / 32;
-    if (pl->MT > 4) return bad("conv2d_b16: more than 128 output channels");
+    pl->MT = (Kc + 31) / 32;
     if ((size_t)2 * std::max(a.G0, a.G1) * d.H * d.W * 16 >= (size_t)1 << 31) return bad("conv2d_b16: sample larger than 2 GB");
     int np = 0;
     // a time-stride-2 transposed layer runs its two column phases as the two column tiles of a workgroup
@@ -1059,7 +1071,9 @@ static bool make_b16_plan(const UnetmiConvDesc& d, B16Plan* pl, std::string* err
     if (wg >= 0x7fffffffull) return bad("conv2d_b16: too many workgroups");
     if (woff >= ((size_t)1 << 31)) return bad("conv2d_b16: weight image larger than 2 GB");
     pl->grid = (unsigned)wg;
-    pl->packed_bytes = woff;
+    a.w_chunk_bytes = (unsigned)woff;
+    pl->packed_bytes = woff * (size_t)pl->kchunks;
+    if (pl->packed_bytes >= ((size_t)1 << 32)) return bad("conv2d_b16: weight image larger than 4 GB");
     return true;
 }
 
@@ -1070,7 +1084,7 @@ static hipError_t launch_b16(Kernel kernel, PerDeviceLatch* raised, const B16Pla
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(pl.grid), dim3(512), pl.lds_bytes, stream, pl.args);
+    hipLaunchKernelGGL(kernel, dim3(pl.grid, pl.kchunks), dim3(512), pl.lds_bytes, stream, pl.args);
     return hipGetLastError();
 }
 
@@ -1114,9 +1128,10 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
     std::memset(packed, 0, pl.packed_bytes);
     const int C = d->C0 + d->C1, K = d->K, KH = d->kh, KW = d->kw, G = a.G0 + a.G1, MT = pl.MT;
     const bool f16 = (d->reserved[2] & UNETMI_B16_IN_F16) != 0;
+    for (int kc = 0; kc < pl.kchunks; ++kc)            // one image per 128-channel output chunk
     for (int q = 0; q < a.nphase; ++q) {
         const B16Phase& p = a.ph[q];
-        unsigned short* img = reinterpret_cast<unsigned short*>(static_cast<char*>(packed) + p.w_off);
+        unsigned short* img = reinterpret_cast<unsigned short*>(static_cast<char*>(packed) + (size_t)kc * a.w_chunk_bytes + p.w_off);
         const int ncp = a.pair ? 2 : 1;
         const int ntws = a.pair ? p.ntw[0] + p.ntw[1] : p.ntw[0];
         for (int g = 0; g < G; ++g)
@@ -1133,8 +1148,8 @@ int unetmi_conv2d_b16_pack_weights(const UnetmiConvDesc* d, const float* w, void
                                             const size_t dst = ((((tap * MT + mt) * 2 + hf) * 32 + row) * 8) + k;
                                             const int cl = (g < a.G0 ? g : g - a.G0) * 16 + hf * 8 + k;
                                             const int ci = g < a.G0 ? (cl < d->C0 ? cl : -1) : (cl < d->C1 ? d->C0 + cl : -1);
-                                            const int co = mt * 32 + row;
-                                            if (ci < 0 || co >= K) continue;
+                                            const int co = kc * 128 + mt * 32 + row;
+                                            if (ci < 0 || co >= K || mt * 32 + row >= a.K) continue;
                                             const size_t src = d->transposed ? (((size_t)ci * K + co) * KH + ky) * KW + kx
                                                                              : (((size_t)co * C + ci) * KH + ky) * KW + kx;
                                             if (f16) {
