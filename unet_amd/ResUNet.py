@@ -41,7 +41,8 @@ def _trunk(net, x, bottleneck=None):
         # recurrence (unet_amd/lstm.py); an LSTM of another shape runs torch's device implementation
         seq = x.reshape(x.shape[0], x.shape[1], x.shape[3]).permute(0, 2, 1)
         if lstm_supported(net.bottleneck):
-            seq = lstm_forward(net.bottleneck, seq.float(), net._lstm_cache).to(x.dtype)
+            seq = lstm_forward(net.bottleneck, seq.float(), net._lstm_cache,
+                               products=getattr(net, "_lstm_products", "fp32")).to(x.dtype)
         else:
             seq = net.bottleneck(seq)[0]
         y = seq.permute(0, 2, 1).reshape(x.shape[0], x.shape[1], 1, x.shape[3]).contiguous()
@@ -165,9 +166,10 @@ class ResUNet(nn.Module):
     bf16_storage = False
     # What else a bfloat16 input selects (default path, bf16_storage False): 1 or 2 = the strided Encoder / Decoder
     # convolutions (3x3 stride (2,1), (4,1) / (3,1) transposed: a third of the fp32 forward's time) run with
-    # bfloat16 OPERANDS on the matrix cores -- 2: weights as bfloat16 plus their rounding remainder -- while every
-    # tensor stays fp32 NCHW and the ResBlocks, the LSTM and the 1x1 paths keep fp32 products; 0 = fp32 products
-    # everywhere (bfloat16 at the boundary only).
+    # 16-bit OPERANDS (fp16: these layers sit behind BatchNorms) on the matrix cores -- 2: weights as two 16-bit
+    # halves -- and so do the LSTM's two time-batched products, while every tensor stays fp32 NCHW and the ResBlocks,
+    # the LSTM's recurrence and the 1x1 paths keep fp32 products; 0 = fp32 products everywhere (bfloat16 at the
+    # boundary only).
     bf16_operands = 1
 
     def forward(self, input):
@@ -178,11 +180,15 @@ class ResUNet(nn.Module):
             blocks = [m for m in self.modules() if isinstance(m, (Encoder, Decoder))] if self.bf16_operands else []
             for m in blocks:
                 m.bf16_operands = int(self.bf16_operands)
+            # ... and the LSTM's two time-batched products (input contributions, projection) take fp16 operands too;
+            # its recurrence stays fp32
+            object.__setattr__(self, "_lstm_products", "fp16" if self.bf16_operands else "fp32")
             try:
                 return self.forward(input.float()).to(torch.bfloat16)
             finally:
                 for m in blocks:
                     m.bf16_operands = 0
+                object.__setattr__(self, "_lstm_products", "fp32")
         B, _, F, T = input.shape
         x = torch.empty((B, 64, F, T), dtype=input.dtype, device=input.device)
         self._input_branch(self.layer_data, "_in_data", input[:, :-2].contiguous(), x, 0)

@@ -63,9 +63,9 @@ class _FusedBlock(nn.Module):
         self._blocked = {}
 
     def _blocked_layers(self, halves):
-        """BlockedConv objects covering this block's output channels in runs of at most 128 (the bf16 kernel's limit;
-        a wider layer is several launches on one converted input, over copies of its parameter slices that are rebuilt
-        when a parameter changes), or False when the block is not one that path serves."""
+        """BlockedConv objects covering this block's output channels: one for a layer of at most 128 outputs or a
+        multiple of 128; any other width runs as several launches on one converted input, over copies of its parameter
+        slices that are rebuilt when a parameter changes.  False when the block is not one that path serves."""
         from .blocked import BlockedConv
         from .fused import activation_code
         conv = getattr(self, self._conv_attr)
@@ -77,10 +77,10 @@ class _FusedBlock(nn.Module):
               and isinstance(self.bn, (nn.BatchNorm2d, nn.Identity))
               and (isinstance(self.bn, nn.Identity) or self.bn.running_mean is not None)
               and code is not None and code[0] in (_lib.ACT_NONE, _lib.ACT_LEAKY, _lib.ACT_RELU)
-              and (K <= 128 or not isinstance(code[1], torch.Tensor) or code[1].numel() == 1))
+              and (K <= 128 or K % 128 == 0 or not isinstance(code[1], torch.Tensor) or code[1].numel() == 1))
         if not ok:
             return False
-        if K <= 128:
+        if K <= 128 or K % 128 == 0:          # one launch (128-channel chunks are a grid dimension of the kernel)
             return [(0, K, BlockedConv(conv, self.bn, self.acti, halves=halves, nchw_out=True))]
         transposed = isinstance(conv, nn.ConvTranspose2d)
         parts = []

@@ -84,10 +84,33 @@ def _pointwise(weight, bias, cache, key):
     return hit[1]
 
 
-def _forward_channel_major(lstm, x, cache):
+def _pointwise16(weight, bias, cache, key):
+    """The same matrix as a 1x1 convolution with fp16 operands (unet_amd/blocked.py: fp32 accumulation, fp32
+    channel-major output), cached on the parameters' versions."""
+    from .blocked import BlockedConv
+    ver = (weight._version, weight.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()))
+    hit = cache.get(key)
+    if hit is None or hit[0] != ver:
+        K, C = weight.shape
+        conv = nn.Conv2d(C, K, 1, bias=True).to(weight.device)
+        with torch.no_grad():
+            conv.weight.copy_(weight.detach().reshape(K, C, 1, 1))
+            conv.bias.copy_(bias.detach()) if bias is not None else conv.bias.zero_()
+        cache[key] = hit = (ver, BlockedConv(conv, None, None, nchw_out=True))
+    layer = hit[1]
+
+    def run(image):                                   # [1, C, T+1, BP] fp32 -> [1, K, T+1, BP] fp32
+        from .blocked import BlockedTensor
+        return layer(BlockedTensor.from_nchw(image, fmt="fp16"))
+    return run
+
+
+def _forward_channel_major(lstm, x, cache, products="fp32"):
     """x [B, T, input] -> [B, T, proj] with every tensor of the layer stack kept as [channels, T+1, BP] (slot 0 =
     the time before the first step): the products are 1x1 convolutions, a layer's projected output is the next
-    layer's input as it stands, and the recurrence kernel reads and writes that layout directly."""
+    layer's input as it stands, and the recurrence kernel reads and writes that layout directly.  ``products``:
+    "fp32" (the exact-fp32 convolution kernel) or "fp16" (the two time-batched products with fp16 operands on the
+    16-bit matrix instruction, for callers whose input was bfloat16 anyway; the recurrence itself stays fp32)."""
     B, T, C = x.shape
     H = lstm.hidden_size
     BP = (B + 15) // 16 * 16
@@ -104,18 +127,21 @@ def _forward_channel_major(lstm, x, cache):
         bhit = cache.get(bkey)
         if bhit is None or bhit[0] != bver:
             cache[bkey] = bhit = (bver, (b_ih.detach().float() + b_hh.detach().float()))
-        gx = _pointwise(w_ih, bhit[1], cache, ("ih", layer))(seq)                 # [1, 4H, T+1, BP]
+        pw = _pointwise16 if (products == "fp16" and w_ih.shape[0] % 128 == 0) else _pointwise
+        gx = pw(w_ih, bhit[1], cache, ("ih", layer, products))(seq)               # [1, 4H, T+1, BP]
         wrec = _folded_recurrent_matrix(lstm, layer, cache)
         hfull = torch.empty((1, H, T + 1, BP), dtype=torch.float32, device=dev)
         hfull[0, :, 0].zero_()
         aborted = aborted | _recurrence(wrec, gx[0], hfull[0], True, channel_major=True)
-        seq = _pointwise(w_hr, None, cache, ("hr", layer))(hfull)                  # [1, proj, T+1, BP]
+        pw = _pointwise16 if (products == "fp16" and (w_hr.shape[0] <= 128 or w_hr.shape[0] % 128 == 0)) else _pointwise
+        seq = pw(w_hr, None, cache, ("hr", layer, products))(hfull)                # [1, proj, T+1, BP]
     out = seq[0, :, 1:, :B].permute(2, 1, 0).contiguous()
     return out, aborted
 
 
-def lstm_forward(lstm, x, cache, _force_grid=False):
-    """x [B, T, input] -> [B, T, proj]; zero initial state, inference only."""
+def lstm_forward(lstm, x, cache, _force_grid=False, products="fp32"):
+    """x [B, T, input] -> [B, T, proj]; zero initial state, inference only.  ``products``: see
+    _forward_channel_major."""
     if not supported(lstm):
         raise NotImplementedError("lstm_forward: built for batch_first projected LSTMs with hidden size 640 or 300")
     if not x.is_cuda or x.dtype != torch.float32:
@@ -124,10 +150,10 @@ def lstm_forward(lstm, x, cache, _force_grid=False):
     use_xcd = _xcd_kernel_fits(x.device, lstm.hidden_size) and not _force_grid
     group = XCD_BATCH_PER_LAUNCH if use_xcd else MAX_BATCH_PER_LAUNCH
     if B > group:                                   # sequences are independent: run them in groups
-        return torch.cat([lstm_forward(lstm, x[i:i + group], cache, _force_grid) for i in range(0, B, group)], dim=0)
+        return torch.cat([lstm_forward(lstm, x[i:i + group], cache, _force_grid, products) for i in range(0, B, group)], dim=0)
     if use_xcd and GEMM == "conv":
         with torch.no_grad(), torch.cuda.device(x.device):
-            out, aborted = _forward_channel_major(lstm, x, cache)
+            out, aborted = _forward_channel_major(lstm, x, cache, products)
             if ON_ABORT == "rerun":
                 if int(aborted.item()) == 0:
                     return out
@@ -135,7 +161,7 @@ def lstm_forward(lstm, x, cache, _force_grid=False):
                 warnings.warn("unet_amd.lstm: the XCD-local recurrence kernel gave up waiting for a workgroup that was "
                               "not resident (GPU shared with other work?); running the call again on the "
                               "device-wide-barrier kernel")
-                return lstm_forward(lstm, x, cache, _force_grid=True)
+                return lstm_forward(lstm, x, cache, _force_grid=True, products=products)
             return torch.where(aborted != 0, torch.full_like(out, float("nan")), out)
     H = lstm.hidden_size
     BP = (B + 15) // 16 * 16
