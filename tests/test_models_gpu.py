@@ -493,8 +493,8 @@ def test_projected_lstm_reruns_on_the_barrier_kernel_after_an_abort(device, monk
     dev = copy.deepcopy(ref).to(device)
     real = L._forward_channel_major
 
-    def aborting(lstm, xx, cache):
-        out, status = real(lstm, xx, cache)
+    def aborting(lstm, xx, cache, products="fp32"):
+        out, status = real(lstm, xx, cache, products)
         return torch.full_like(out, float("nan")), torch.ones_like(status)
 
     monkeypatch.setattr(L, "_forward_channel_major", aborting)
