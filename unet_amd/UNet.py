@@ -99,10 +99,18 @@ def blocked_shell_layers(net):
         # The network input (an STFT of unknown scale) and the first encoder's operands stay bfloat16 -- that layer
         # takes its weights as two bfloat16 halves, it is bound by its activation traffic anyway -- and with
         # operand_format "fp16" (default) every tensor behind its BatchNorm is stored, and multiplied, as fp16.
+        # A one-channel 1x1 head on a one-channel last decoder is a scalar affine map: that decoder then writes plain
+        # fp32 [B, 1, F, T] from its accumulators (4 bytes per pixel instead of a 16-byte record that a further launch
+        # would read back) and the head is applied elementwise.
+        lin = net.linear
+        scalar_head = lin.in_channels == 1 and lin.out_channels == 1 and lin.kernel_size == (1, 1) and \
+            lin.stride == (1, 1) and lin.padding == (0, 0) and net.decoders[-1].transconv.out_channels == 1
+        n_dec = len(net.decoders)
         built = dict(enc=[BlockedConv(m.conv, m.bn, m.acti, halves=2 if i == 0 else 1, out_fmt=fmt)
                           for i, m in enumerate(net.encoders)],
-                     dec=[BlockedConv(m.transconv, m.bn, m.acti, out_fmt=fmt) for m in net.decoders],
-                     head=BlockedConv(net.linear, None, None, nchw_out=True))
+                     dec=[BlockedConv(m.transconv, m.bn, m.acti, out_fmt=fmt,
+                                      nchw_out=scalar_head and i == n_dec - 1) for i, m in enumerate(net.decoders)],
+                     head=None if scalar_head else BlockedConv(lin, None, None, nchw_out=True))
     object.__setattr__(net, "_blocked", (fmt, built))
     return built
 
@@ -124,6 +132,9 @@ def blocked_shell_forward(net, layers, x):
         if i == last:
             break
         skip = skips[last - i]
+    if layers["head"] is None:
+        lin = net.linear
+        return t.mul_(lin.weight.detach().reshape(())).add_(lin.bias.detach().reshape(()) if lin.bias is not None else 0.0)
     return layers["head"](t)
 
 
