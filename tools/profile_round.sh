@@ -13,5 +13,6 @@ step "headline write requests" timeout -s KILL 300 rocprofv3 --output-format csv
 step "ResUNet kernel trace" timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_resunet -o res -- python3 $R/tools/bench_configs.py --only resunet --steps 5 --warmup 2 > $O/${TAG}_resunet.json 2> $O/${TAG}_resunet.err
 step "ResUNet bf16 kernel trace" timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_resunet_bf16 -o res -- python3 $R/tools/bench_configs.py --only resunet --dtype bf16 --steps 5 --warmup 2 > $O/${TAG}_resunet_bf16.json 2> $O/${TAG}_resunet_bf16.err
 step "DSUNet bf16 kernel trace" timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_dsunet_bf16 -o ds -- python3 $R/tools/bench_configs.py --only dsunet --dtype bf16 --steps 5 --warmup 2 > $O/${TAG}_dsunet_bf16.json 2> $O/${TAG}_dsunet_bf16.err
+step "UNet bf16 kernel trace" timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_unet_bf16 -o un -- python3 $R/tools/bench_configs.py --only unet --dtype bf16 --steps 5 --warmup 2 > $O/${TAG}_unet_bf16.json 2> $O/${TAG}_unet_bf16.err
 step "train step kernel trace" timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_train -o tr -- python3 $R/bench.py --mode train --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_train.json 2> $O/${TAG}_train.err
 echo done
