@@ -111,13 +111,22 @@ def blocked_shell_layers(net):
                      dec=[BlockedConv(m.transconv, m.bn, m.acti, out_fmt=fmt,
                                       nchw_out=scalar_head and i == n_dec - 1) for i, m in enumerate(net.decoders)],
                      head=None if scalar_head else BlockedConv(lin, None, None, nchw_out=True))
+        # A head of at most 32 outputs takes the network's mask activation in its epilogue (the kernels with the
+        # transcendental activations are built for one 32-channel tile): one pass less over the fp32 mask.
+        mask_act = getattr(net, "activation_mask", None)
+        built["head_has_mask"] = False
+        if not scalar_head and lin.out_channels <= 32 and mask_act is not None:
+            code = activation_code(mask_act)
+            if code is not None and code[0] not in (_lib.ACT_NONE, _lib.ACT_LEAKY, _lib.ACT_RELU):
+                built["head"] = BlockedConv(lin, None, mask_act, nchw_out=True)
+                built["head_has_mask"] = True
     object.__setattr__(net, "_blocked", (fmt, built))
     return built
 
 
 def blocked_shell_forward(net, layers, x):
     """The concat shell on channel-blocked 16-bit tensors; returns the head's fp32 [B, K, F, T] output before the mask
-    activation.  (Fusing UNet's 1x1 head into the last decoder, as DSUNet does, was measured: the one-column-tile
+    activation -- or after it when ``layers["head_has_mask"]`` says the head's epilogue applied it.  (Fusing UNet's 1x1 head into the last decoder, as DSUNet does, was measured: the one-column-tile
     kernel a fused head needs makes the batch-64 forward 7.5 ms instead of 7.3, at the same error.)"""
     from .blocked import BlockedTensor
     t = BlockedTensor.from_nchw(x.contiguous())
@@ -169,7 +178,8 @@ class UNet(nn.Module):
         if x.dtype == torch.bfloat16 and self.bf16_matrix and not self.training:
             layers = blocked_shell_layers(self)
             if layers:
-                return self.activation_mask(blocked_shell_forward(self, layers, x)).to(x.dtype)
+                p = blocked_shell_forward(self, layers, x)
+                return (p if layers["head_has_mask"] else self.activation_mask(p)).to(x.dtype)
         p = concat_shell_forward(self, x)
         if self.training:
             from . import _lib

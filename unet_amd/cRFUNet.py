@@ -45,7 +45,9 @@ class UNet20(nn.Module):
         require_device_tensor(x, "UNet20")
         layers = blocked_shell_layers(self) if (x.dtype == torch.bfloat16 and self.bf16_matrix and not self.training) else False
         if layers:
-            f = self.activation_mask(blocked_shell_forward(self, layers, x))     # fp32 [B, 2*c_out*N, F, T]
+            f = blocked_shell_forward(self, layers, x)                            # fp32 [B, 2*c_out*N, F, T]
+            if not layers["head_has_mask"]:
+                f = self.activation_mask(f)
         else:
             p = concat_shell_forward(self, x)
             if self._head is None:
