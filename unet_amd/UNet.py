@@ -167,7 +167,7 @@ class UNet(nn.Module):
     # bfloat16 inputs: 16-bit operands on the matrix cores over the channel-blocked layout when every layer is one that
     # kernel serves (False: the NCHW bfloat16-storage kernels with fp32 products).  operand_format "fp16" (default):
     # the input and the first encoder's operands stay bfloat16, every tensor behind its BatchNorm is fp16.  At the
-    # benchmark's size (batch 64, T=509) against the fp32 CPU forward: 7.3 ms, relative L2 2.3e-3, max-norm 7.8e-3;
+    # benchmark's size (batch 64, T=509) against the fp32 CPU forward: 7.2 ms, relative L2 2.3e-3, max-norm 7.8e-3;
     # with "bf16" operands throughout 7.0 ms, 7.2e-3 / 4.2e-2; the storage-only path 46 ms, 5.4e-3 / 3.1e-2; the
     # fp32 forward 35.2 ms.
     bf16_matrix = True
