@@ -76,6 +76,11 @@ CASES = [
     (128, 0, 384, (3, 1), (1, 1), (0, 0), (0, 0), False, 5, 70),
     (384, 0, 128, (3, 1), (1, 1), (0, 0), (0, 0), True, 3, 40),
     (48, 0, 256, (1, 1), (1, 1), (0, 0), (0, 0), False, 9, 33),
+    # time stride 2 on odd and tiny widths, one and two column tiles, a time-only stride, an even kernel width
+    (64, 0, 64, (7, 5), (2, 2), (3, 2), (0, 0), False, 21, 75),
+    (32, 0, 40, (3, 3), (1, 2), (1, 1), (0, 0), False, 9, 141),
+    (16, 0, 16, (1, 4), (1, 2), (0, 1), (0, 0), False, 3, 9),
+    (16, 0, 16, (3, 5), (2, 2), (1, 2), (0, 0), False, 5, 2),
     # edges: one pixel, one channel, tiles hanging over every border, time-only stride, dilation via a wide pad
     (1, 0, 1, (1, 1), (1, 1), (0, 0), (0, 0), False, 1, 1),
     (3, 0, 2, (3, 3), (1, 1), (1, 1), (0, 0), False, 2, 3),
