@@ -919,3 +919,29 @@ def test_gru_recurrence(device, n_in, hidden, B, T, with_state, gemm, monkeypatc
     assert not torch.isnan(got).any(), "the recurrence kernel aborted"
     assert_close(got, want, tol=2e-5, what="GRU outputs")
     assert_close(got_h, want_h, tol=2e-5, what="GRU final state")
+
+
+@pytest.mark.gpu
+def test_fp16_overflow_is_seen_and_recomputed(device):
+    """The fp16-operand chain does not clip: a BatchNorm scaled so that its layer's output passes +-65504 gives
+    infinities.  on_fp16_overflow = "nan" returns that result as it is; the default "rerun" warns, recomputes the call with
+    bfloat16 operands (the same numbers as operand_format = "bf16") and leaves the module's format as it was."""
+    import unet_amd
+    dev = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=32))
+    unet_amd.seeded_fill_(dev, seed=5)
+    with torch.no_grad():
+        dev.encoders[1].bn.weight.mul_(3e5)
+    dev.eval().to(device)
+    x = torch.randn(2, 2, 257, 29, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).to(device)
+    with torch.no_grad():
+        dev.on_fp16_overflow = "nan"
+        raw = dev(x)
+        assert not bool(torch.isfinite(raw.float()).all()), "the scaled layer did not overflow fp16: the test tests nothing"
+        dev.on_fp16_overflow = "rerun"
+        with pytest.warns(UserWarning, match="fp16-operand"):
+            got = dev(x)
+        assert dev.operand_format == "fp16"
+        dev.operand_format = "bf16"
+        want = dev(x)
+    assert bool(torch.isfinite(got.float()).all())
+    assert torch.equal(got, want)

@@ -395,6 +395,9 @@ class DSUNet(nn.Module):
         # infinity and shows as NaN in the mask (set "bf16" for such a model);
         # "bf16" keeps bfloat16 throughout (then the last decoder takes two weight halves as well).
         self.operand_format = "fp16"
+        # a non-finite mask from the fp16 chain: "rerun" that call with bfloat16 operands (one host synchronisation
+        # per call to look), or "nan" to return it as it is (unet_amd/blocked.py:fp16_overflow_guard)
+        self.on_fp16_overflow = "rerun"
 
     def _blocked_layers(self):
         """BlockedConv per encoder / decoder / head, or False when a layer is outside that kernel."""
@@ -456,7 +459,9 @@ class DSUNet(nn.Module):
         if sf.dtype == torch.bfloat16 and self.bf16_matrix and not self.training:
             layers = self._blocked_layers()
             if layers:
-                return self._forward_blocked(layers, sf, attract)
+                from .blocked import fp16_overflow_guard
+                return fp16_overflow_guard(self, self._forward_blocked(layers, sf, attract),
+                                           lambda: self._forward_blocked(self._blocked_layers(), sf, attract))
         skips = []
         for i, enc in enumerate(self.encoders):
             skips.append(self.res[i](sf) if i != L - 1 else sf)

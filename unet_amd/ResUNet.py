@@ -171,24 +171,39 @@ class ResUNet(nn.Module):
     # the LSTM's recurrence and the 1x1 paths keep fp32 products; 0 = fp32 products everywhere (bfloat16 at the
     # boundary only).
     bf16_operands = 1
+    # a non-finite result of that path: "rerun" the call with fp32 products (one host synchronisation per call to look),
+    # or "nan" to return it as it is
+    on_fp16_overflow = "rerun"
 
     def forward(self, input):
         require_device_tensor(input, "ResUNet")
         if self.training:
             return self._forward_train(input)
         if input.dtype == torch.bfloat16 and not self.bf16_storage:
-            blocks = [m for m in self.modules() if isinstance(m, (Encoder, Decoder))] if self.bf16_operands else []
-            for m in blocks:
-                m.bf16_operands = int(self.bf16_operands)
-            # ... and the LSTM's two time-batched products (input contributions, projection) take fp16 operands too;
-            # its recurrence stays fp32
-            object.__setattr__(self, "_lstm_products", "fp16" if self.bf16_operands else "fp32")
-            try:
-                return self.forward(input.float()).to(torch.bfloat16)
-            finally:
+            def run(operands):
+                blocks = [m for m in self.modules() if isinstance(m, (Encoder, Decoder))] if operands else []
                 for m in blocks:
-                    m.bf16_operands = 0
-                object.__setattr__(self, "_lstm_products", "fp32")
+                    m.bf16_operands = int(operands)
+                # ... and the LSTM's two time-batched products (input contributions, projection) take fp16 operands
+                # too; its recurrence stays fp32
+                object.__setattr__(self, "_lstm_products", "fp16" if operands else "fp32")
+                try:
+                    return self.forward(input.float()).to(torch.bfloat16)
+                finally:
+                    for m in blocks:
+                        m.bf16_operands = 0
+                    object.__setattr__(self, "_lstm_products", "fp32")
+            out = run(self.bf16_operands)
+            if self.on_fp16_overflow not in ("rerun", "nan"):
+                raise ValueError("on_fp16_overflow is 'rerun' or 'nan'")
+            # fp16 operands do not clip: a tensor beyond +-65504 in front of one of those layers gives infinities
+            if self.bf16_operands and self.on_fp16_overflow == "rerun" and not bool(torch.isfinite(out).all()):
+                import warnings
+                warnings.warn("ResUNet: non-finite values behind the fp16-operand layers (an activation beyond +-65504, "
+                              "or a non-finite input); recomputing this call with fp32 products -- set bf16_operands = 0 "
+                              "to make that the default")
+                out = run(0)
+            return out
         B, _, F, T = input.shape
         x = torch.empty((B, 64, F, T), dtype=input.dtype, device=input.device)
         self._input_branch(self.layer_data, "_in_data", input[:, :-2].contiguous(), x, 0)

@@ -639,6 +639,7 @@ class UDSS(nn.Module):
         # weights' precision (measured against the fp32 CPU forward).
         self.bf16_matrix = False
         self.operand_format = "fp16"
+        self.on_fp16_overflow = "rerun"       # or "nan": unet_amd/blocked.py:fp16_overflow_guard
         # "bf16" format only: 2 = each weight goes in as bfloat16 + its rounding remainder (two MFMAs); with 1 the
         # L2 error is 1.04e-2
         self.bf16_weight_halves = 2
@@ -659,7 +660,9 @@ class UDSS(nn.Module):
             if self.bf16_matrix and isinstance(self.BTN, nn.Identity) and all(
                     isinstance(m.bn, ComplexBatchNorm2d) and isinstance(m.relu, (nn.LeakyReLU, nn.PReLU))
                     for m in list(self.encoders) + list(self.decoders)):
-                return self._forward_blocked(sf, attract)
+                from .blocked import fp16_overflow_guard
+                return fp16_overflow_guard(self, self._forward_blocked(sf, attract),
+                                           lambda: self._forward_blocked(sf, attract))
             sf = sf.float()
         x = stack_complex(sf)
         skips = []

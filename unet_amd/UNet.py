@@ -172,14 +172,19 @@ class UNet(nn.Module):
     # fp32 forward 35.2 ms.
     bf16_matrix = True
     operand_format = "fp16"
+    on_fp16_overflow = "rerun"        # or "nan": unet_amd/blocked.py:fp16_overflow_guard
 
     def forward(self, x):
         require_device_tensor(x, "UNet")
         if x.dtype == torch.bfloat16 and self.bf16_matrix and not self.training:
             layers = blocked_shell_layers(self)
             if layers:
-                p = blocked_shell_forward(self, layers, x)
-                return (p if layers["head_has_mask"] else self.activation_mask(p)).to(x.dtype)
+                def run():
+                    ls = blocked_shell_layers(self)
+                    p = blocked_shell_forward(self, ls, x)
+                    return (p if ls["head_has_mask"] else self.activation_mask(p)).to(x.dtype)
+                from .blocked import fp16_overflow_guard
+                return fp16_overflow_guard(self, run(), run)
         p = concat_shell_forward(self, x)
         if self.training:
             from . import _lib

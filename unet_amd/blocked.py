@@ -23,6 +23,32 @@ from . import ops as _ops
 blocks_for = _ops.blocks_for
 
 
+def fp16_overflow_guard(module, out, rerun):
+    """What a network on the fp16-operand chain does with a result that is not finite.  fp16 stores do not clip: an
+    activation beyond +-65504 becomes infinity and reaches the output as NaN.  ``module.on_fp16_overflow``:
+    "rerun" (default) tests the result (one reduction and one host synchronisation per call) and, when it holds a
+    non-finite value, warns and recomputes it with ``module.operand_format = "bf16"`` for that call (``rerun()`` is the
+    module's own blocked forward; it reads the format from the module); "nan" returns the result as it is, without the
+    synchronisation."""
+    mode = getattr(module, "on_fp16_overflow", "rerun")
+    if mode not in ("rerun", "nan"):
+        raise ValueError("on_fp16_overflow is 'rerun' or 'nan'")
+    if mode == "nan" or getattr(module, "operand_format", "bf16") != "fp16":
+        return out
+    probe = torch.view_as_real(out) if out.is_complex() else out
+    if bool(torch.isfinite(probe).all()):
+        return out
+    import warnings
+    warnings.warn("{}: non-finite values behind the fp16-operand chain (an activation beyond +-65504, or a non-finite "
+                  "input); recomputing this call with bfloat16 operands -- set operand_format = 'bf16' to make that "
+                  "the default".format(type(module).__name__))
+    object.__setattr__(module, "operand_format", "bf16")
+    try:
+        return rerun()
+    finally:
+        object.__setattr__(module, "operand_format", "fp16")
+
+
 class BlockedTensor:
     __slots__ = ("data", "C")
 

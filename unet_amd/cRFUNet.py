@@ -40,14 +40,18 @@ class UNet20(nn.Module):
     # NCHW kernels: 28.2 ms, 3.3e-3 / 6.0e-3)
     bf16_matrix = True
     operand_format = "fp16"
+    on_fp16_overflow = "rerun"        # or "nan": unet_amd/blocked.py:fp16_overflow_guard
 
     def forward(self, x):
         require_device_tensor(x, "UNet20")
         layers = blocked_shell_layers(self) if (x.dtype == torch.bfloat16 and self.bf16_matrix and not self.training) else False
         if layers:
-            f = blocked_shell_forward(self, layers, x)                            # fp32 [B, 2*c_out*N, F, T]
-            if not layers["head_has_mask"]:
-                f = self.activation_mask(f)
+            def run():
+                ls = blocked_shell_layers(self)
+                f = blocked_shell_forward(self, ls, x)                            # fp32 [B, 2*c_out*N, F, T]
+                return f if ls["head_has_mask"] else self.activation_mask(f)
+            from .blocked import fp16_overflow_guard
+            f = fp16_overflow_guard(self, run(), run)
         else:
             p = concat_shell_forward(self, x)
             if self._head is None:
