@@ -924,16 +924,25 @@ def test_gru_recurrence(device, n_in, hidden, B, T, with_state, gemm, monkeypatc
 @pytest.mark.gpu
 def test_fp16_overflow_is_seen_and_recomputed(device):
     """The fp16-operand chain does not clip: a BatchNorm scaled so that its layer's output passes +-65504 gives
-    infinities.  on_fp16_overflow = "nan" returns that result as it is; the default "rerun" warns, recomputes the call with
-    bfloat16 operands (the same numbers as operand_format = "bf16") and leaves the module's format as it was."""
+    infinities.  on_fp16_overflow = "nan" returns that result as it is; "rerun" warns, recomputes the call with bfloat16
+    operands (the same numbers as operand_format = "bf16") and leaves the module's format as it was; the default
+    "defer" takes no host synchronisation: the first overflowing call returns its result, the next call that finds the
+    check arrived warns, switches the module to bfloat16 operands and returns the right numbers."""
     import unet_amd
     dev = unet_amd.UNet(*unet_amd.default_unet_blocks(c_in=2, c_last=1, f_dim=32))
     unet_amd.seeded_fill_(dev, seed=5)
-    with torch.no_grad():
-        dev.encoders[1].bn.weight.mul_(3e5)
+    assert dev.on_fp16_overflow == "defer"
     dev.eval().to(device)
     x = torch.randn(2, 2, 257, 29, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).to(device)
     with torch.no_grad():
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                 # a healthy model: two deferred checks, no warning
+            fine = dev(x)
+            torch.cuda.synchronize()
+            assert torch.equal(dev(x), fine) and dev.operand_format == "fp16"
+        dev.encoders[1].bn.weight.mul_(3e5)
+        dev._blocked = None                                # the folded BatchNorm is cached per parameter version
         dev.on_fp16_overflow = "nan"
         raw = dev(x)
         assert not bool(torch.isfinite(raw.float()).all()), "the scaled layer did not overflow fp16: the test tests nothing"
@@ -941,7 +950,14 @@ def test_fp16_overflow_is_seen_and_recomputed(device):
         with pytest.warns(UserWarning, match="fp16-operand"):
             got = dev(x)
         assert dev.operand_format == "fp16"
-        dev.operand_format = "bf16"
+        dev.on_fp16_overflow = "defer"
+        torch.cuda.synchronize()
+        first = dev(x)                                     # the healthy call's check has arrived and is read: fine
+        assert not bool(torch.isfinite(first.float()).all()) and dev.operand_format == "fp16"
+        torch.cuda.synchronize()
+        with pytest.warns(UserWarning, match="an earlier call"):
+            second = dev(x)
+        assert dev.operand_format == "bf16"
         want = dev(x)
     assert bool(torch.isfinite(got.float()).all())
-    assert torch.equal(got, want)
+    assert torch.equal(got, want) and torch.equal(second, want)

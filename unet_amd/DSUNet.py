@@ -395,9 +395,8 @@ class DSUNet(nn.Module):
         # infinity and shows as NaN in the mask (set "bf16" for such a model);
         # "bf16" keeps bfloat16 throughout (then the last decoder takes two weight halves as well).
         self.operand_format = "fp16"
-        # a non-finite mask from the fp16 chain: "rerun" that call with bfloat16 operands (one host synchronisation
-        # per call to look), or "nan" to return it as it is (unet_amd/blocked.py:fp16_overflow_guard)
-        self.on_fp16_overflow = "rerun"
+        # a non-finite mask from the fp16 chain: unet_amd/blocked.py:fp16_overflow_guard ("defer" | "rerun" | "nan")
+        self.on_fp16_overflow = "defer"
 
     def _blocked_layers(self):
         """BlockedConv per encoder / decoder / head, or False when a layer is outside that kernel."""

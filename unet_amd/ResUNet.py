@@ -171,9 +171,9 @@ class ResUNet(nn.Module):
     # the LSTM's recurrence and the 1x1 paths keep fp32 products; 0 = fp32 products everywhere (bfloat16 at the
     # boundary only).
     bf16_operands = 1
-    # a non-finite result of that path: "rerun" the call with fp32 products (one host synchronisation per call to look),
-    # or "nan" to return it as it is
-    on_fp16_overflow = "rerun"
+    # a non-finite result of that path: unet_amd/blocked.py:fp16_overflow_guard ("defer" | "rerun" | "nan"); the safe
+    # operands here are fp32 products (bf16_operands = 0)
+    on_fp16_overflow = "defer"
 
     def forward(self, input):
         require_device_tensor(input, "ResUNet")
@@ -193,17 +193,17 @@ class ResUNet(nn.Module):
                     for m in blocks:
                         m.bf16_operands = 0
                     object.__setattr__(self, "_lstm_products", "fp32")
-            out = run(self.bf16_operands)
-            if self.on_fp16_overflow not in ("rerun", "nan"):
-                raise ValueError("on_fp16_overflow is 'rerun' or 'nan'")
             # fp16 operands do not clip: a tensor beyond +-65504 in front of one of those layers gives infinities
-            if self.bf16_operands and self.on_fp16_overflow == "rerun" and not bool(torch.isfinite(out).all()):
-                import warnings
-                warnings.warn("ResUNet: non-finite values behind the fp16-operand layers (an activation beyond +-65504, "
-                              "or a non-finite input); recomputing this call with fp32 products -- set bf16_operands = 0 "
-                              "to make that the default")
-                out = run(0)
-            return out
+            from .blocked import fp16_overflow_guard
+            keep = self.bf16_operands
+
+            def set_safe():
+                self.bf16_operands = 0
+
+            def unset_safe():
+                self.bf16_operands = keep
+            return fp16_overflow_guard(self, run(self.bf16_operands), lambda: run(self.bf16_operands),
+                                       active=bool(self.bf16_operands), set_safe=set_safe, unset_safe=unset_safe)
         B, _, F, T = input.shape
         x = torch.empty((B, 64, F, T), dtype=input.dtype, device=input.device)
         self._input_branch(self.layer_data, "_in_data", input[:, :-2].contiguous(), x, 0)

@@ -639,7 +639,7 @@ class UDSS(nn.Module):
         # weights' precision (measured against the fp32 CPU forward).
         self.bf16_matrix = False
         self.operand_format = "fp16"
-        self.on_fp16_overflow = "rerun"       # or "nan": unet_amd/blocked.py:fp16_overflow_guard
+        self.on_fp16_overflow = "defer"       # or "rerun", "nan": unet_amd/blocked.py:fp16_overflow_guard
         # "bf16" format only: 2 = each weight goes in as bfloat16 + its rounding remainder (two MFMAs); with 1 the
         # L2 error is 1.04e-2
         self.bf16_weight_halves = 2

@@ -23,30 +23,65 @@ from . import ops as _ops
 blocks_for = _ops.blocks_for
 
 
-def fp16_overflow_guard(module, out, rerun):
+def fp16_overflow_guard(module, out, rerun, active=None, set_safe=None, unset_safe=None):
     """What a network on the fp16-operand chain does with a result that is not finite.  fp16 stores do not clip: an
     activation beyond +-65504 becomes infinity and reaches the output as NaN.  ``module.on_fp16_overflow``:
-    "rerun" (default) tests the result (one reduction and one host synchronisation per call) and, when it holds a
-    non-finite value, warns and recomputes it with ``module.operand_format = "bf16"`` for that call (``rerun()`` is the
-    module's own blocked forward; it reads the format from the module); "nan" returns the result as it is, without the
-    synchronisation."""
-    mode = getattr(module, "on_fp16_overflow", "rerun")
-    if mode not in ("rerun", "nan"):
-        raise ValueError("on_fp16_overflow is 'rerun' or 'nan'")
-    if mode == "nan" or getattr(module, "operand_format", "bf16") != "fp16":
+
+    "defer" (default)  no host synchronisation: the sum of the result (non-finite exactly when an element is) travels
+                       to pinned host memory behind the call, and the NEXT call that finds it arrived reads it.  A
+                       non-finite sum raises a warning, switches the module to its safe operands for good
+                       (``operand_format = "bf16"``; ResUNet: fp32 products) and that call is recomputed with them
+                       -- so the first overflowing call returns its non-finite result, later ones are right.  A
+                       check still in flight is not overtaken: calls issued meanwhile are not looked at.
+    "rerun"            one host synchronisation per call: a non-finite result is recomputed with the safe operands
+                       before it is returned (with a warning); the module keeps its format.
+    "nan"              the result is returned as it is.
+
+    ``rerun()`` is the module's own forward on that path (it reads the format from the module); ``set_safe`` /
+    ``unset_safe`` switch the module to and from its safe operands (default: ``operand_format``)."""
+    mode = getattr(module, "on_fp16_overflow", "defer")
+    if mode not in ("defer", "rerun", "nan"):
+        raise ValueError("on_fp16_overflow is 'defer', 'rerun' or 'nan'")
+    if active is None:
+        active = getattr(module, "operand_format", "bf16") == "fp16"
+    if mode == "nan" or not active:
         return out
-    probe = torch.view_as_real(out) if out.is_complex() else out
-    if bool(torch.isfinite(probe).all()):
-        return out
+    if set_safe is None:
+        def set_safe():
+            object.__setattr__(module, "operand_format", "bf16")
+
+        def unset_safe():
+            object.__setattr__(module, "operand_format", "fp16")
+    import math
     import warnings
-    warnings.warn("{}: non-finite values behind the fp16-operand chain (an activation beyond +-65504, or a non-finite "
-                  "input); recomputing this call with bfloat16 operands -- set operand_format = 'bf16' to make that "
-                  "the default".format(type(module).__name__))
-    object.__setattr__(module, "operand_format", "bf16")
-    try:
-        return rerun()
-    finally:
-        object.__setattr__(module, "operand_format", "fp16")
+    what = ("{}: non-finite values behind the fp16-operand layers (an activation beyond +-65504, or a non-finite "
+            "input); ".format(type(module).__name__))
+    probe = torch.view_as_real(out) if out.is_complex() else out
+    if mode == "rerun":
+        if math.isfinite(float(probe.sum(dtype=torch.float32))):
+            return out
+        warnings.warn(what + "recomputing this call with the safe operands")
+        set_safe()
+        try:
+            return rerun()
+        finally:
+            unset_safe()
+    state = module.__dict__.get("_fp16_check")           # [pinned host scalar, event, in flight]
+    if state is None:
+        state = [torch.zeros((), dtype=torch.float32, pin_memory=True), torch.cuda.Event(), False]
+        object.__setattr__(module, "_fp16_check", state)
+    if state[2]:
+        if not state[1].query():
+            return out                                   # the earlier check has not arrived yet
+        state[2] = False
+        if not math.isfinite(float(state[0])):
+            warnings.warn(what + "an earlier call returned them; this call and the following ones use the safe operands")
+            set_safe()
+            return rerun()
+    state[0].copy_(probe.sum(dtype=torch.float32), non_blocking=True)
+    state[1].record()
+    state[2] = True
+    return out
 
 
 class BlockedTensor:
