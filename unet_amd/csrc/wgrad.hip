@@ -32,7 +32,7 @@ int api_fail(int code, const std::string& msg);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTQ = 32;          // pixels of a P row handled per step
-constexpr int kPPitch = 36;      // LDS pitch of a P row (4 x odd: the A-operand read is conflict-free)
+constexpr int kPPitch = 34;      // LDS pitch of a P row (2 mod 4: lanes (a, q) of a 32-lane half read banks 2a + q)
 constexpr int kMaxQ = 12;        // Q elements staged per thread per step
 constexpr int kMaxPairs = 36;    // (b-tile, tap) pairs per workgroup = 4 waves x 9
 
@@ -44,7 +44,7 @@ struct WgradArgs {
     int N, A0, A1, A, B, PH, PW, QH, QW, kh, kw, sh, sw, ph, pw, dh, dw;
     int BT;          // b-channels per workgroup (multiple of 16)
     int qcols;       // staged columns of a Q row: (kTQ-1)*sw + (kw-1)*dw + 1
-    int qpitch;      // LDS pitch of a Q row (4 x odd)
+    int qpitch;      // LDS pitch of a Q row (2 mod 4)
     int R;           // rows of the ring
     int win;         // rows a step reads: (kh-1)*dh + 1
     int nqc;         // column strips per sample
@@ -408,10 +408,10 @@ static hipError_t launch_wgrad_thin(const WgradArgs& a, const ThinWgradPlan& t, 
     return hipGetLastError();
 }
 
-static int round_pitch(int cols) {          // smallest 4 x odd >= cols
-    int p = (cols + 3) / 4;
-    if (!(p & 1)) ++p;
-    return p * 4;
+static int round_pitch(int cols) {          // smallest pitch >= cols that is 2 mod 4 (see kPPitch)
+    int p = cols;
+    while ((p & 3) != 2) ++p;
+    return p;
 }
 
 static int plan_wgrad(int N, int A0, int A1, int B, int PH, int PW, int QH, int QW, int kh, int kw, int sh, int sw,
