@@ -61,6 +61,10 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, int voff, i
 
 constexpr int kOob = (int)0x80000000;     // byte offset beyond any buffer: the load returns 0
 
+#ifndef WG_ABLATE
+#define WG_ABLATE 0     // timing builds only (tools/wgrad_probe.py): 1 no global loads, 2 no LDS stores in the loop, 4 no MFMAs, 8 no step barrier
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
     extern __shared__ float lds[];
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
         float rp[8], rq[kMaxQ];
         auto load_p = [&](int p) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) rp[i] = buf_load(rs_p, p_voff[i], p * g.PW * 4);
+            for (int i = 0; i < 8; ++i) rp[i] = (WG_ABLATE & 1) ? (float)p : buf_load(rs_p, p_voff[i], p * g.PW * 4);
         };
         auto store_p = [&](int b2) {
 #pragma unroll
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 #pragma unroll
             for (int i = 0; i < kMaxQ; ++i) {
                 const int y = y0 + q_rs[i];
-                rq[i] = buf_load(rs_q, ((unsigned)y < (unsigned)g.QH && q_rs[i] >= 0) ? q_voff[i] + y * g.QW * 4 : kOob, 0);
+                rq[i] = (WG_ABLATE & 1) ? (float)y : buf_load(rs_q, ((unsigned)y < (unsigned)g.QH && q_rs[i] >= 0) ? q_voff[i] + y * g.QW * 4 : kOob, 0);
             }
         };
         auto store_q = [&](int y0) {
@@ -208,15 +212,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
                 for (int j = 0; j < NT; ++j) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][t], bv[cur][j], acc[j][t], 0, 0, 0);
+                        if (!(WG_ABLATE & 4)) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][t], bv[cur][j], acc[j][t], 0, 0, 0);
+                        else acc[j][t][0] += av[cur][t] * bv[cur][j];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) {
+            if (more && !(WG_ABLATE & 2)) {
                 store_p(buf ^ 1);
                 store_q(ynew);
             }
-            __syncthreads();
+            if (!(WG_ABLATE & 8)) __syncthreads();
             buf ^= 1;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
