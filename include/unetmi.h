@@ -282,7 +282,10 @@ int unetmi_gru_bptt(int T, int BP, int H, const float* whh, float* gates, const 
  * channel_major = 1 takes gx as [4H][T+1][BP] (slot t+1 = step t; slot 0 is not read) and writes hfull as
  * [H][T+1][BP]: the layouts in which the two matrix products around the recurrence are 1x1 convolutions of
  * unetmi_conv2d_fwd over a [channels, T+1, BP] image (gx = W_ih * x + b; h = W_hr * hfull), so a layer's output
- * is the next layer's input without a transpose. */
+ * is the next layer's input without a transpose.  channel_major is a flags word: bit 0 as above, bit 1 (value 2)
+ * = the recurrent product of each step with fp16 operands (wrec and the previous state rounded to fp16 for the matrix
+ * instruction, a quarter of the step's matrix work; accumulation, gates, cell and state stay fp32), for callers
+ * whose sequence was rounded to 16 bits anyway. */
 size_t unetmi_lstm_recurrence_xcd_workspace_bytes(void);
 int unetmi_lstm_recurrence_xcd(int T, int BP, int H, const float* wrec, const float* gx, float* hfull,
                                int channel_major, void* ws, size_t ws_bytes, void* stream);

@@ -475,6 +475,37 @@ def test_projected_lstm_matches_torch_cpu(device, B, T, kernel, gemm, monkeypatc
     assert_close(got, want, tol=2e-5, what="projected LSTM")
 
 
+@pytest.mark.parametrize("hidden,proj,B,T", [(640, 384, 32, 64), (640, 384, 5, 501), (300, 192, 7, 40)])
+def test_projected_lstm_fp16_products_and_recurrence(device, hidden, proj, B, T):
+    """products = "fp16" (what ResUNet selects for a bfloat16 input): the two time-batched products and the recurrent
+    product of every step with fp16 operands, all sums and the state in fp32, against torch's CPU LSTM -- within 2e-3 of
+    the output range (measured: a few 1e-4; the bfloat16 rounding of such a caller's input alone is 4e-3), and
+    closer to it than 1e-2 after 501 steps (errors do not build up along the sequence)."""
+    import copy
+
+    import unet_amd
+    import unet_amd.lstm as L
+    from unet_amd.seeding import normal
+    ref = torch.nn.LSTM(proj, hidden, 3 if hidden == 640 else 2, batch_first=True, proj_size=proj)
+    holder = torch.nn.Module()
+    holder.lstm = ref
+    unet_amd.seeded_fill_(holder, seed=72)
+    x = normal("lstm16/x", (B, T, proj), seed=72)
+    with torch.no_grad():
+        want = ref(x)[0]
+    dev = copy.deepcopy(ref).to(device)
+    assert L.FP16_RECURRENCE
+    got = L.lstm_forward(dev, x.to(device), {}, products="fp16")
+    exact = L.lstm_forward(dev, x.to(device), {})
+    assert not torch.isnan(got).any(), "the recurrence kernel aborted"
+    err = float((got.cpu() - want).abs().max() / want.abs().max())
+    last = float((got.cpu()[:, -8:] - want[:, -8:]).abs().max() / want.abs().max())
+    print("projected LSTM hidden {} T={} fp16 products + recurrence: max-norm {:.3e} (last 8 steps {:.3e}); fp32 path {:.3e}".format(
+        hidden, T, err, last, float((exact.cpu() - want).abs().max() / want.abs().max())))
+    assert err <= 2e-3 and last <= 2e-3
+    assert not torch.equal(got, exact), "the fp16 path was not taken"
+
+
 def test_projected_lstm_reruns_on_the_barrier_kernel_after_an_abort(device, monkeypatch):
     """When the XCD-local recurrence reports that a wait gave up, lstm_forward computes the call again on the
     device-wide-barrier kernel (default ON_ABORT = "rerun") instead of returning NaN; "nan" keeps the NaN.  The

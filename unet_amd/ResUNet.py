@@ -167,9 +167,9 @@ class ResUNet(nn.Module):
     # What else a bfloat16 input selects (default path, bf16_storage False): 1 or 2 = the strided Encoder / Decoder
     # convolutions (3x3 stride (2,1), (4,1) / (3,1) transposed: a third of the fp32 forward's time) run with
     # 16-bit OPERANDS (fp16: these layers sit behind BatchNorms) on the matrix cores -- 2: weights as two 16-bit
-    # halves -- and so do the LSTM's two time-batched products, while every tensor stays fp32 NCHW and the ResBlocks,
-    # the LSTM's recurrence and the 1x1 paths keep fp32 products; 0 = fp32 products everywhere (bfloat16 at the
-    # boundary only).
+    # halves -- and so do the LSTM's two time-batched products and the recurrent product of each of its steps (sums,
+    # gates, cell and state stay fp32), while every tensor stays fp32 NCHW and the ResBlocks and the 1x1 paths keep
+    # fp32 products; 0 = fp32 products everywhere (bfloat16 at the boundary only).
     bf16_operands = 1
     # a non-finite result of that path: unet_amd/blocked.py:fp16_overflow_guard ("defer" | "rerun" | "nan"); the safe
     # operands here are fp32 products (bf16_operands = 0)
@@ -184,8 +184,8 @@ class ResUNet(nn.Module):
                 blocks = [m for m in self.modules() if isinstance(m, (Encoder, Decoder))] if operands else []
                 for m in blocks:
                     m.bf16_operands = int(operands)
-                # ... and the LSTM's two time-batched products (input contributions, projection) take fp16 operands
-                # too; its recurrence stays fp32
+                # ... and the LSTM's products (input contributions, projection, the recurrent product of each step)
+                # take fp16 operands too; its sums, gates, cell and state stay fp32
                 object.__setattr__(self, "_lstm_products", "fp16" if operands else "fp32")
                 try:
                     return self.forward(input.float()).to(torch.bfloat16)

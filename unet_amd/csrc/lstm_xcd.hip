@@ -37,6 +37,7 @@ namespace unetmi {
 int api_fail(int code, const std::string& msg);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // The kernels are instantiated per PADDED hidden size HP: 640 (ResUNet's bottleneck: 32 workgroups per XCD) and 320
 // (hidden size 300 of ResUNetOnFreq / LSTMBlock, ResUNet.py:335, UNet_m.py:587-610: 16 workgroups per XCD).  Units
@@ -71,8 +72,12 @@ __device__ __forceinline__ float dpp_add(float v) {     // v + (v moved by the D
 
 // SAVE: also keep what backpropagation through time needs -- the four activated gates of every step (written over
 // the step's input contribution: a.gates may be a.gx) and the cell state.
-template <bool SAVE, int kXH>
+// F16: the recurrent product Wrec * m_{t-1} takes fp16 operands (v_mfma_f32_4x4x4_16b_f16: four k per instruction, a
+// quarter of the 200 fp32 instructions of a step; fp32 accumulation, gates, cell and published state stay fp32).  For
+// callers whose input was rounded to 16 bits anyway: |m| < 1 and the folded matrix is O(1/sqrt(H)), well inside fp16.
+template <bool SAVE, int kXH, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
+    static_assert(!(SAVE && F16), "the training form keeps fp32 operands");
     constexpr int kXWg = kXH / kXU;          // workgroups (compute units) used per XCD
     constexpr int kXKg = kXH / 4 / 4;        // k-groups per wave: HP/4 columns / 4 per instruction
     constexpr int kXLd = kXH / 64;           // state granules a lane reads per step
@@ -95,13 +100,26 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
     // ---- lane roles.  lane = 16*ui + 4*ki + r: A operand row r = gate r of unit ui of the set, B/D column r ----
     const int ui = lane >> 4, ki = (lane >> 2) & 3, r = lane & 3;
     const int u_base = slot * kXU;
-    float A[kXSets][kXKg];
+    constexpr int kXKq = kXKg / 4;           // fp16 form: k-blocks of 4 x 4 columns per wave
+    float A[F16 ? 1 : kXSets][F16 ? 1 : kXKg];
+    f16x4 A16[F16 ? kXSets : 1][F16 ? kXKq : 1];      // lane (unit ui, k-group ki, gate r): columns 16*kq + 4*ki .. +3 of its wave's quarter
 #pragma unroll
     for (int s = 0; s < kXSets; ++s) {
-        const int u = u_base + 4 * s + ui, k0 = kXH / 4 * wave + ki;
-        const float* row = a.wrec + (size_t)(r * a.H + u) * a.H + k0;
+        const int u = u_base + 4 * s + ui;
+        if constexpr (F16) {
+            const int k0 = kXH / 4 * wave + 4 * ki;
+            const float* row = a.wrec + (size_t)(r * a.H + u) * a.H + k0;
 #pragma unroll
-        for (int kg = 0; kg < kXKg; ++kg) A[s][kg] = (u < a.H && k0 + 4 * kg < a.H) ? row[4 * kg] : 0.f;
+            for (int kq = 0; kq < kXKq; ++kq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    A16[s][kq][e] = (_Float16)((u < a.H && k0 + 16 * kq + e < a.H) ? row[16 * kq + e] : 0.f);
+        } else {
+            const int k0 = kXH / 4 * wave + ki;
+            const float* row = a.wrec + (size_t)(r * a.H + u) * a.H + k0;
+#pragma unroll
+            for (int kg = 0; kg < kXKg; ++kg) A[s][kg] = (u < a.H && k0 + 4 * kg < a.H) ? row[4 * kg] : 0.f;
+        }
     }
     // gate thread: cell (unit ul, column cj) of this workgroup; a padding unit (>= H) only publishes zeros
     const bool gate_thread = tid < kXU * kXCols;
@@ -139,8 +157,17 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
                 ok = ok && (unsigned)(g >> 32) == (unsigned)t;
             }
             if (__all(ok)) {
+                if constexpr (F16) {                 // [column][k] halves: a lane's four k of one column are one 8-byte read
+                    _Float16* sh16 = reinterpret_cast<_Float16*>(sh);
 #pragma unroll
-                for (int i = 0; i < kXLd; ++i) sh[lane + 64 * i] = v[i];
+                    for (int i = 0; i < kXLd; ++i) {
+                        const int e = lane + 64 * i;
+                        sh16[(e & 3) * (kXH / 4) + (e >> 2)] = (_Float16)v[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kXLd; ++i) sh[lane + 64 * i] = v[i];
+                }
                 break;
             }
             if ((++spins & 63u) == 0u) {
@@ -156,6 +183,17 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
         f32x4 acc[kXSets];
 #pragma unroll
         for (int s = 0; s < kXSets; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (F16) {
+            const _Float16* sh16 = reinterpret_cast<const _Float16*>(sh) + r * (kXH / 4) + 4 * ki;
+            f16x4 bq[kXKq];
+#pragma unroll
+            for (int kq = 0; kq < kXKq; ++kq) bq[kq] = *reinterpret_cast<const f16x4*>(sh16 + 16 * kq);
+#pragma unroll
+            for (int kq = 0; kq < kXKq; ++kq)
+#pragma unroll
+                for (int s = 0; s < kXSets; ++s)
+                    acc[s] = __builtin_amdgcn_mfma_f32_4x4x4f16(A16[s][kq], bq[kq], acc[s], 0, 0, 0);
+        } else {
         // The state operands are read a group of 8 k-blocks ahead into a second register set: one read waited for
         // in front of each 10 MFMAs (80 cycles) put ~19 LDS round trips on the critical path of every time step.
         constexpr int kGrp = kXKg % 8 == 0 ? 8 : 4;
@@ -177,6 +215,7 @@ __global__ __launch_bounds__(256, 1) void lstm_xcd_kernel(const LstmXcdArgs a) {
                 for (int s = 0; s < kXSets; ++s)
                     acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[s][gi * kGrp + q], bv[cur][q], acc[s], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         // sum the 4 k-blocks of a unit (lanes 4*ki apart inside a row of 16), leave the partials in LDS
         float* part = &s_part[t & 1][wave][0][0][0];
@@ -437,24 +476,27 @@ static int lstm_xcd_device_ok(const char* who, int H, int BP) {
     return UNETMI_OK;
 }
 
-template <bool SAVE, int HP>
+template <bool SAVE, int HP, bool F16 = false>
 static int lstm_xcd_launch(const LstmXcdArgs& a, void* ws, hipStream_t s) {
     int per_cu = 0;
-    const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_kernel<SAVE, HP>, 256, 0);
+    const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_xcd_kernel<SAVE, HP, F16>, 256, 0);
     if (oe != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd occupancy query: ") + hipGetErrorString(oe));
     if (per_cu < 1) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: the kernel does not fit a compute unit");
     // tickets, abort word and the state granules start from zero: h_0 = 0 carrying step tag 0
     hipError_t e = hipMemsetAsync(ws, 0, unetmi_lstm_recurrence_xcd_workspace_bytes(), s);
     if (e != hipSuccess) return api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd memset: ") + hipGetErrorString(e));
-    hipLaunchKernelGGL((lstm_xcd_kernel<SAVE, HP>), dim3(kXcds * (HP / kXU)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((lstm_xcd_kernel<SAVE, HP, F16>), dim3(kXcds * (HP / kXU)), dim3(256), 0, s, a);
     e = hipGetLastError();
     return e == hipSuccess ? UNETMI_OK : api_fail(UNETMI_E_HIP, std::string("lstm_recurrence_xcd launch: ") + hipGetErrorString(e));
 }
 
-static int lstm_xcd_run(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, int channel_major,
+static int lstm_xcd_run(int T, int BP, int H, const float* wrec, const float* gx, float* hfull, int layout,
                         float* gates, float* cell, void* ws, size_t ws_bytes, void* stream) {
     if (T < 0 || BP < 1 || H < 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence_xcd: bad sizes");
-    if (channel_major != 0 && channel_major != 1) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence_xcd: layout is 0 or 1");
+    if (layout < 0 || layout > 3) return api_fail(UNETMI_E_BAD_DESC, "lstm_recurrence_xcd: layout is 0 .. 3 (bit 0: channel-major, bit 1: fp16 operands)");
+    const int channel_major = layout & 1;
+    const bool f16 = (layout & 2) != 0;
+    if (f16 && gates) return api_fail(UNETMI_E_UNSUPPORTED, "lstm_recurrence_xcd: the training form keeps fp32 operands");
     const int ok = lstm_xcd_device_ok("lstm_recurrence_xcd", H, BP);
     if (ok != UNETMI_OK) return ok;
     if (T == 0) return UNETMI_OK;
@@ -474,6 +516,7 @@ static int lstm_xcd_run(int T, int BP, int H, const float* wrec, const float* gx
     a.ctl = static_cast<unsigned*>(ws);
     a.hx = reinterpret_cast<unsigned long long*>(static_cast<unsigned*>(ws) + 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (f16) return H == 640 ? lstm_xcd_launch<false, 640, true>(a, ws, s) : lstm_xcd_launch<false, 320, true>(a, ws, s);
     if (H == 640) return gates ? lstm_xcd_launch<true, 640>(a, ws, s) : lstm_xcd_launch<false, 640>(a, ws, s);
     return gates ? lstm_xcd_launch<true, 320>(a, ws, s) : lstm_xcd_launch<false, 320>(a, ws, s);
 }

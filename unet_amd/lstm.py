@@ -54,10 +54,15 @@ def _xcd_kernel_fits(dev, hidden):
     return KERNEL == "xcd" and hidden in (640, 300) and torch.cuda.get_device_properties(dev).multi_processor_count == 256
 
 
-def _recurrence(wrec, gx, hfull, use_xcd, channel_major=False):
+def _recurrence(wrec, gx, hfull, use_xcd, channel_major=False, f16=False):
     """One layer's T dependent steps (torch.ops.unetmi.lstm_recurrence); returns the kernel's status word
     (a device scalar, non-zero = aborted)."""
-    return _ops.lstm_recurrence(wrec, gx, hfull, bool(use_xcd), bool(channel_major))
+    return _ops.lstm_recurrence(wrec, gx, hfull, bool(use_xcd), bool(channel_major), bool(f16))
+
+
+# With products = "fp16" the recurrent matrix-vector product of every step takes fp16 operands as well (fp32
+# accumulation, gates, cell and state): a quarter of the step's matrix instructions.  False keeps that product fp32.
+FP16_RECURRENCE = True
 
 
 # The two matrix products around the recurrence -- the input contributions of all steps, and the projection of all
@@ -110,7 +115,8 @@ def _forward_channel_major(lstm, x, cache, products="fp32"):
     the time before the first step): the products are 1x1 convolutions, a layer's projected output is the next
     layer's input as it stands, and the recurrence kernel reads and writes that layout directly.  ``products``:
     "fp32" (the exact-fp32 convolution kernel) or "fp16" (the two time-batched products with fp16 operands on the
-    16-bit matrix instruction, for callers whose input was bfloat16 anyway; the recurrence itself stays fp32)."""
+    16-bit matrix instruction, for callers whose input was bfloat16 anyway; with FP16_RECURRENCE the recurrent product of
+    each step takes fp16 operands too -- every sum, the gates, the cell and the state stay fp32)."""
     B, T, C = x.shape
     H = lstm.hidden_size
     BP = (B + 15) // 16 * 16
@@ -132,7 +138,8 @@ def _forward_channel_major(lstm, x, cache, products="fp32"):
         wrec = _folded_recurrent_matrix(lstm, layer, cache)
         hfull = torch.empty((1, H, T + 1, BP), dtype=torch.float32, device=dev)
         hfull[0, :, 0].zero_()
-        aborted = aborted | _recurrence(wrec, gx[0], hfull[0], True, channel_major=True)
+        aborted = aborted | _recurrence(wrec, gx[0], hfull[0], True, channel_major=True,
+                                        f16=products == "fp16" and FP16_RECURRENCE)
         pw = _pointwise16 if (products == "fp16" and (w_hr.shape[0] <= 128 or w_hr.shape[0] % 128 == 0)) else _pointwise
         seq = pw(w_hr, None, cache, ("hr", layer, products))(hfull)                # [1, proj, T+1, BP]
     out = seq[0, :, 1:, :B].permute(2, 1, 0).contiguous()

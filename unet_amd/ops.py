@@ -502,7 +502,7 @@ _LIBRARY.define("adam_step(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Te
                 "float beta2, float eps, float weight_decay, float grad_scale, int step) -> ()")
 _LIBRARY.define("gather_f32(Tensor src, Tensor map) -> Tensor")
 _LIBRARY.define("dwconv2d_wgrad(Tensor x, Tensor? x2, Tensor dout, int[] kernel, int[] padding, int[] dilation) -> (Tensor, Tensor)")
-_LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool xcd, bool channel_major) -> Tensor")
+_LIBRARY.define("lstm_recurrence(Tensor wrec, Tensor gx, Tensor(a!) hfull, bool xcd, bool channel_major, bool f16=False) -> Tensor")
 _LIBRARY.define("lstm_recurrence_train(Tensor wrec, Tensor(a!) gx, Tensor(b!) hfull, Tensor(c!) cell) -> Tensor")
 _LIBRARY.define("lstm_bptt(Tensor wrec, Tensor(a!) gates, Tensor cell, Tensor dhfull) -> Tensor")
 _LIBRARY.define("gru_recurrence(Tensor whh, Tensor bhh, Tensor gx, Tensor(a!) hfull, bool channel_major) -> Tensor")
@@ -669,11 +669,12 @@ def _gather_f32_cuda(src, map):
 _lstm_scratch = {}
 
 
-def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major):
+def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major, f16=False):
     """One layer's T dependent steps with the folded recurrent matrix wrec [4H, H].  Step-major: gx [T, 4H, BP]
     (input contributions + bias), hfull [T+1, HP, BP], HP = H rounded up to 16 (slot 0 = initial state, slots 1..
     are filled; rows H..HP-1 must be zero).  Channel-major
-    (XCD kernel only): gx [4H, T+1, BP] with slot t+1 = step t, hfull [H, T+1, BP].  Returns the kernel's status
+    (XCD kernel only): gx [4H, T+1, BP] with slot t+1 = step t, hfull [H, T+1, BP].  f16 (XCD kernel only): the
+    recurrent product takes fp16 operands (fp32 accumulation and state).  Returns the kernel's status
     word as a device scalar (non-zero: a wait gave up and the remaining steps are NaN)."""
     for t, name in ((wrec, "wrec"), (gx, "gx"), (hfull, "hfull")):
         _dev(t, name, "lstm_recurrence")
@@ -685,6 +686,8 @@ def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major):
         T, G, BP = gx.shape
         H = G // 4
         ok = tuple(hfull.shape) == (T + 1, (H + 15) // 16 * 16, BP)       # a slot's rows are padded to a multiple of 16
+    if f16 and not xcd:
+        raise ValueError("unetmi::lstm_recurrence: fp16 operands are built into the XCD-local kernel only")
     if not ok or G != 4 * H or tuple(wrec.shape) != (G, H):
         raise ValueError("unetmi::lstm_recurrence: wrec [4H,H] with gx [T,4H,BP], hfull [T+1,H,BP], or (XCD kernel) "
                          "gx [4H,T+1,BP], hfull [H,T+1,BP] expected")
@@ -696,7 +699,8 @@ def _lstm_recurrence_cuda(wrec, gx, hfull, xcd, channel_major):
             ws = _lstm_scratch.get(key)
             if ws is None:
                 ws = _lstm_scratch[key] = torch.empty(nbytes // 4, dtype=torch.int32, device=gx.device)
-            check(_lib.lib.unetmi_lstm_recurrence_xcd(T, BP, H, _ptr(wrec), _ptr(gx), _ptr(hfull), int(channel_major),
+            check(_lib.lib.unetmi_lstm_recurrence_xcd(T, BP, H, _ptr(wrec), _ptr(gx), _ptr(hfull),
+                                                      int(channel_major) | (2 if f16 else 0),
                                                       _ptr(ws), nbytes, stream), "unetmi_lstm_recurrence_xcd")
             return ws[8].clone()
         sync = _lstm_scratch.get(key)
@@ -1064,7 +1068,7 @@ def _(src, map):
 
 
 @torch.library.register_fake("unetmi::lstm_recurrence")
-def _(wrec, gx, hfull, xcd, channel_major):
+def _(wrec, gx, hfull, xcd, channel_major, f16=False):
     return gx.new_empty((), dtype=torch.int32)
 
 
